@@ -1,0 +1,117 @@
+/*
+ * sfa.h -- C ABI of libsfa.so: MI355X (gfx950) sink flash attention.
+ *
+ * This is the drop-in boundary for the hot path of
+ * RulinShao/sink-flash-attention-kernel.  Each entry point replaces one Triton
+ * launch site (plus the eager PyTorch epilogue next to it) of the reference;
+ * citations are <file>:<line> relative to the reference repository.
+ *
+ *   sfa_fwd      replaces  sink_attention/sink_flash_attention.py:537-554
+ *                          (_sink_flash_attn_fwd_kernel, :93-194)
+ *   sfa_bwd      replaces  sink_attention/sink_flash_attention.py:581-665
+ *                          (Delta at :582, _sink_flash_attn_bwd_dkdv_kernel :256-364,
+ *                           _sink_flash_attn_bwd_dq_kernel :371-484, the GQA group sum
+ *                           :648-651 and ds_aux :658-665)
+ *   sfa_decode   replaces  sink_attention/decode_kernel.py:175-226
+ *                          (_decode_split_kv_kernel :28-113 and the PyTorch phase-2
+ *                           reduction :201-226)
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, ints.  No torch / C++ types cross the boundary.
+ *   - The library never allocates, frees or synchronises.  The caller owns every
+ *     buffer (outputs and workspaces included) and passes DEVICE pointers.
+ *   - Every launch goes to the hipStream_t passed as `stream` (void* here so the
+ *     header needs no HIP include); the caller makes the right device current.
+ *   - Re-entrant, no global mutable state except a thread-local error string.
+ *   - Return value: 0 = ok, <0 = SFA_ERR_* (argument / support problem, nothing
+ *     was launched), >0 = a hipError_t from a launch.
+ *   - Tensors are described by sfa_tensor: 4-D [B, H, N, D] with strides in
+ *     ELEMENTS.  Any B/H/N strides are accepted (so a [B, N, H, D] activation can be
+ *     passed as a permuted view without a copy); the D stride must be 1.
+ */
+#ifndef SFA_H
+#define SFA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFA_ABI_VERSION 1
+
+/* element types of q/k/v/o/do/dq/dk/dv (all tensors of one call share one dtype) */
+#define SFA_DTYPE_F32 0
+#define SFA_DTYPE_F16 1
+#define SFA_DTYPE_BF16 2
+
+#define SFA_OK 0
+#define SFA_ERR_INVALID_ARGUMENT (-1)  /* null pointer, shape mismatch, bad stride ...   */
+#define SFA_ERR_UNSUPPORTED (-2)       /* e.g. head dim beyond what any kernel handles   */
+#define SFA_ERR_WORKSPACE (-3)         /* workspace too small / null                      */
+
+/* flags */
+#define SFA_FLAG_FORCE_GENERIC 0x1u /* use the exact-f32 generic kernels even when an MFMA kernel exists */
+
+typedef struct sfa_tensor {
+    void* ptr;         /* device pointer to element [0,0,0,0]                    */
+    int64_t shape[4];  /* B, H, N, D                                             */
+    int64_t stride[4]; /* in elements; stride[3] must be 1                       */
+    int32_t dtype;     /* SFA_DTYPE_*                                            */
+    int32_t reserved;
+} sfa_tensor;
+
+int sfa_abi_version(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* sfa_last_error(void);
+
+/* Thread-local name of the kernel family the last successful call on this thread
+ * dispatched to, e.g. "fwd_mfma_bf16_d128", "fwd_generic_f32".  For tests/benchmarks. */
+const char* sfa_last_path(void);
+
+/*
+ * Forward.  valid(i,j) = (j <= i) && (j < num_sink || j >= i - window + 1)
+ *   q,o  [B, Hq, N, D]     k,v [B, Hkv, N, D]   Hq % Hkv == 0
+ *   lse  [B, Hq, N] float32, contiguous: log-sum-exp of the scaled scores of the row
+ *        INCLUDING the s_aux logit (-inf for a row that sees nothing)
+ *   s_aux  nullable, [Hq] float32: per-head extra logit that only enters the denominator
+ *   scale  softmax scale (the reference hard-wires 1/sqrt(D), sink_flash_attention.py:505)
+ */
+int sfa_fwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+            float* lse, const float* s_aux, int num_sink, int window, float scale,
+            unsigned flags, void* stream);
+
+/*
+ * Backward.  Inputs q,k,v,o,do,lse,s_aux as produced/consumed by sfa_fwd.
+ *   dq [B,Hq,N,D]; dk,dv [B,Hkv,N,D] (already summed over the GQA group);
+ *   ds_aux nullable [Hq] float32 (required non-null iff s_aux non-null).
+ *   workspace: sfa_bwd_workspace_bytes() bytes of device scratch, 256-byte aligned.
+ *   Deterministic: the same inputs give bitwise-identical outputs.
+ */
+size_t sfa_bwd_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t N, int64_t D, int dtype,
+                               int num_sink, int window, unsigned flags);
+
+int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+            const sfa_tensor* d_o, const float* lse, const float* s_aux, const sfa_tensor* dq,
+            const sfa_tensor* dk, const sfa_tensor* dv, float* ds_aux, void* workspace,
+            size_t workspace_bytes, int num_sink, int window, float scale, unsigned flags,
+            void* stream);
+
+/*
+ * Single-query decode over every key handed in (no mask; windowing is the cache's job,
+ * decode_kernel.py:72-83).
+ *   q,o [B, Hq, 1, D]   k,v [B, Hkv, Nkv, D]   s_aux nullable [Hq] float32
+ */
+size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D,
+                                  int dtype);
+
+int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+               const float* s_aux, void* workspace, size_t workspace_bytes, float scale,
+               unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFA_H */

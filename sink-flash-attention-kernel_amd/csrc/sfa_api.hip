@@ -1,0 +1,210 @@
+// extern "C" entry points of libsfa.so (declared in include/sfa.h): argument
+// validation, kernel-family choice, workspace carving.  No allocation, no sync.
+#include <cmath>
+#include <cstring>
+
+#include "sfa_common.hpp"
+#include "sfa_internal.hpp"
+
+namespace sfa {
+
+static thread_local char g_err[512] = "";
+static thread_local char g_path[128] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void set_path(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_path, sizeof(g_path), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+int check_tensor(const sfa_tensor* t, const char* name) {
+    SFA_CHECK_ARG(t != nullptr, "%s: null tensor descriptor", name);
+    SFA_CHECK_ARG(t->dtype == SFA_DTYPE_F32 || t->dtype == SFA_DTYPE_F16 || t->dtype == SFA_DTYPE_BF16,
+                  "%s: unknown dtype %d", name, t->dtype);
+    for (int i = 0; i < 4; ++i) SFA_CHECK_ARG(t->shape[i] >= 0, "%s: negative shape[%d]", name, i);
+    const bool empty = t->shape[0] == 0 || t->shape[1] == 0 || t->shape[2] == 0 || t->shape[3] == 0;
+    SFA_CHECK_ARG(empty || t->ptr != nullptr, "%s: null data pointer", name);
+    SFA_CHECK_ARG(t->shape[3] <= 1 || t->stride[3] == 1, "%s: last-dim stride must be 1 (got %lld)", name,
+                  (long long)t->stride[3]);
+    for (int i = 0; i < 3; ++i)
+        SFA_CHECK_ARG(t->stride[i] >= 0, "%s: negative stride[%d] not supported", name, i);
+    return SFA_OK;
+}
+
+int same_shape(const sfa_tensor* a, const sfa_tensor* b, const char* an, const char* bn) {
+    for (int i = 0; i < 4; ++i)
+        SFA_CHECK_ARG(a->shape[i] == b->shape[i], "%s and %s differ in shape[%d]: %lld vs %lld", an, bn, i,
+                      (long long)a->shape[i], (long long)b->shape[i]);
+    SFA_CHECK_ARG(a->dtype == b->dtype, "%s and %s differ in dtype", an, bn);
+    return SFA_OK;
+}
+
+// shape contract of SinkFlashAttentionFunc.forward (sink_flash_attention.py:494-498)
+int check_prefill(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, Problem* p, int num_sink,
+                  int window, float scale) {
+    int st;
+    if ((st = check_tensor(q, "q")) || (st = check_tensor(k, "k")) || (st = check_tensor(v, "v"))) return st;
+    if ((st = same_shape(k, v, "k", "v"))) return st;
+    SFA_CHECK_ARG(q->dtype == k->dtype, "q and k differ in dtype");
+    SFA_CHECK_ARG(q->shape[0] == k->shape[0], "batch mismatch: q %lld vs k %lld", (long long)q->shape[0],
+                  (long long)k->shape[0]);
+    SFA_CHECK_ARG(q->shape[2] == k->shape[2], "prefill needs N_q == N_kv (q %lld, k %lld)", (long long)q->shape[2],
+                  (long long)k->shape[2]);
+    SFA_CHECK_ARG(q->shape[3] == k->shape[3], "head dim mismatch");
+    SFA_CHECK_ARG(k->shape[1] > 0 && q->shape[1] % k->shape[1] == 0, "H_q (%lld) must be divisible by H_kv (%lld)",
+                  (long long)q->shape[1], (long long)k->shape[1]);
+    SFA_CHECK_ARG(q->shape[2] < (1ll << 30) && q->shape[0] * q->shape[1] < (1ll << 30), "problem too large");
+    SFA_CHECK_ARG(num_sink >= 0, "num_sink must be >= 0");
+    SFA_CHECK_ARG(std::isfinite(scale), "scale must be finite");
+    p->B = (int)q->shape[0];
+    p->Hq = (int)q->shape[1];
+    p->Hkv = (int)k->shape[1];
+    p->N = (int)q->shape[2];
+    p->D = (int)q->shape[3];
+    p->num_sink = num_sink;
+    p->window = window;
+    p->scale = scale;
+    return SFA_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct BwdWorkspace {
+    size_t delta_off, dsaux_off, mfma_off, total;
+};
+
+BwdWorkspace bwd_layout(const Problem& p, int dtype, bool use_mfma) {
+    BwdWorkspace w;
+    size_t off = 0;
+    w.delta_off = off;
+    off += align256((size_t)p.B * p.Hq * p.N * sizeof(float));
+    w.dsaux_off = off;
+    off += align256((size_t)p.B * p.Hq * (size_t)bwd_preprocess_nblk(p.N) * sizeof(float));
+    w.mfma_off = off;
+    if (use_mfma) off += align256(bwd_mfma_workspace_bytes(p, dtype));
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+}  // namespace sfa
+
+using namespace sfa;
+
+extern "C" {
+
+int sfa_abi_version(void) { return SFA_ABI_VERSION; }
+const char* sfa_last_error(void) { return g_err; }
+const char* sfa_last_path(void) { return g_path; }
+
+int sfa_fwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
+            const float* s_aux, int num_sink, int window, float scale, unsigned flags, void* stream) {
+    g_err[0] = 0;
+    Problem p;
+    int st = check_prefill(q, k, v, &p, num_sink, window, scale);
+    if (st) return st;
+    if ((st = check_tensor(o, "o")) || (st = same_shape(q, o, "q", "o"))) return st;
+    if (p.B == 0 || p.Hq == 0 || p.N == 0) return SFA_OK;
+    SFA_CHECK_ARG(p.D > 0, "head dim must be > 0");
+    SFA_CHECK_ARG(lse != nullptr, "lse: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!(flags & SFA_FLAG_FORCE_GENERIC) && fwd_mfma_supported(q->dtype, p.D))
+        return fwd_mfma(q, k, v, o, lse, s_aux, p, s);
+    return fwd_generic(q, k, v, o, lse, s_aux, p, s);
+}
+
+size_t sfa_bwd_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t N, int64_t D, int dtype, int num_sink,
+                               int window, unsigned flags) {
+    Problem p{(int)B, (int)Hq, (int)Hkv, (int)N, (int)D, num_sink, window, 1.f};
+    const bool use_mfma = !(flags & SFA_FLAG_FORCE_GENERIC) && bwd_mfma_supported(dtype, (int)D);
+    return bwd_layout(p, dtype, use_mfma).total;
+}
+
+int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+            const sfa_tensor* d_o, const float* lse, const float* s_aux, const sfa_tensor* dq, const sfa_tensor* dk,
+            const sfa_tensor* dv, float* ds_aux, void* workspace, size_t workspace_bytes, int num_sink, int window,
+            float scale, unsigned flags, void* stream) {
+    g_err[0] = 0;
+    Problem p;
+    int st = check_prefill(q, k, v, &p, num_sink, window, scale);
+    if (st) return st;
+    if ((st = check_tensor(o, "o")) || (st = same_shape(q, o, "q", "o"))) return st;
+    if ((st = check_tensor(d_o, "do")) || (st = same_shape(q, d_o, "q", "do"))) return st;
+    if ((st = check_tensor(dq, "dq")) || (st = same_shape(q, dq, "q", "dq"))) return st;
+    if ((st = check_tensor(dk, "dk")) || (st = same_shape(k, dk, "k", "dk"))) return st;
+    if ((st = check_tensor(dv, "dv")) || (st = same_shape(v, dv, "v", "dv"))) return st;
+    if (p.B == 0 || p.Hq == 0 || p.N == 0) return SFA_OK;
+    SFA_CHECK_ARG(p.D > 0, "head dim must be > 0");
+    SFA_CHECK_ARG(lse != nullptr, "lse: null pointer");
+    SFA_CHECK_ARG((s_aux == nullptr) == (ds_aux == nullptr), "ds_aux must be given iff s_aux is");
+    const bool use_mfma = !(flags & SFA_FLAG_FORCE_GENERIC) && bwd_mfma_supported(q->dtype, p.D);
+    const BwdWorkspace w = bwd_layout(p, q->dtype, use_mfma);
+    if (workspace == nullptr || workspace_bytes < w.total || ((uintptr_t)workspace & 255) != 0) {
+        set_error("bwd workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", w.total, workspace_bytes,
+                  workspace);
+        return SFA_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* delta = reinterpret_cast<float*>((char*)workspace + w.delta_off);
+    float* dsaux_part = reinterpret_cast<float*>((char*)workspace + w.dsaux_off);
+    st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s);
+    if (st) return st;
+    if (use_mfma) return bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, s);
+    return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, s);
+}
+
+size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype) {
+    DecodePlan pl;
+    if (decode_plan(B, Hq, Hkv, Nkv, D, dtype, &pl) != SFA_OK) return 0;
+    return align256((size_t)B * Hq * pl.splits * (size_t)(D + 2) * sizeof(float));
+}
+
+int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+               const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
+               void* stream) {
+    (void)flags;
+    g_err[0] = 0;
+    int st;
+    if ((st = check_tensor(q, "q")) || (st = check_tensor(k, "k")) || (st = check_tensor(v, "v")) ||
+        (st = check_tensor(o, "o")))
+        return st;
+    if ((st = same_shape(k, v, "k", "v")) || (st = same_shape(q, o, "q", "o"))) return st;
+    SFA_CHECK_ARG(q->dtype == k->dtype, "q and k differ in dtype");
+    // decode_kernel.py:146-147
+    SFA_CHECK_ARG(q->shape[2] == 1, "sink_decode_attention requires N_q=1, got %lld", (long long)q->shape[2]);
+    SFA_CHECK_ARG(q->shape[0] == k->shape[0] && q->shape[3] == k->shape[3], "q/k batch or head-dim mismatch");
+    SFA_CHECK_ARG(k->shape[1] > 0 && q->shape[1] % k->shape[1] == 0, "H_q (%lld) must be divisible by H_kv (%lld)",
+                  (long long)q->shape[1], (long long)k->shape[1]);
+    SFA_CHECK_ARG(std::isfinite(scale), "scale must be finite");
+    SFA_CHECK_ARG(k->shape[2] < (1ll << 31) - 4096, "N_kv too large");
+    if (q->shape[0] == 0 || q->shape[1] == 0) return SFA_OK;
+    DecodePlan pl;
+    st = decode_plan(q->shape[0], q->shape[1], k->shape[1], k->shape[2], q->shape[3], q->dtype, &pl);
+    if (st) return st;
+    const int es = dtype_size(q->dtype);
+    const sfa_tensor* ts[3] = {q, k, v};
+    for (const sfa_tensor* t : ts) {
+        SFA_CHECK_ARG(((uintptr_t)t->ptr % 16) == 0 && (t->stride[0] * es) % 16 == 0 && (t->stride[1] * es) % 16 == 0 &&
+                          (t->stride[2] * es) % 16 == 0,
+                      "decode: q/k/v rows must be 16-byte aligned");
+    }
+    const size_t need = sfa_decode_workspace_bytes(q->shape[0], q->shape[1], k->shape[1], k->shape[2], q->shape[3],
+                                                  q->dtype);
+    if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 255) != 0) {
+        set_error("decode workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", need, workspace_bytes,
+                  workspace);
+        return SFA_ERR_WORKSPACE;
+    }
+    return decode_launch(q, k, v, o, s_aux, workspace, scale, pl, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Shared host/device helpers for libsfa (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "sfa.h"
+
+namespace sfa {
+
+// ---------------------------------------------------------------- host side
+void set_error(const char* fmt, ...);
+void set_path(const char* fmt, ...);
+
+#define SFA_CHECK_ARG(cond, ...)             \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::sfa::set_error(__VA_ARGS__);   \
+            return SFA_ERR_INVALID_ARGUMENT; \
+        }                                    \
+    } while (0)
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return SFA_OK;
+}
+
+// A [B,H,N,D] view with element strides (D stride == 1), passed to kernels by value.
+struct View {
+    char* ptr;
+    int64_t sb, sh, sn;  // element strides
+};
+
+inline View make_view(const sfa_tensor* t) {
+    return View{(char*)t->ptr, t->stride[0], t->stride[1], t->stride[2]};
+}
+
+// Problem description shared by the prefill kernels.
+struct Problem {
+    int B, Hq, Hkv, N, D;
+    int num_sink, window;
+    float scale;
+};
+
+inline int dtype_size(int dt) { return dt == SFA_DTYPE_F32 ? 4 : 2; }
+
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device side
+using bf16_t = __hip_bfloat16;
+using f16_t = __half;
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int id = SFA_DTYPE_F32; };
+template <> struct DT<f16_t> { static constexpr int id = SFA_DTYPE_F16; };
+template <> struct DT<bf16_t> { static constexpr int id = SFA_DTYPE_BF16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(f16_t x) { return __half2float(x); }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __bfloat162float(x); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return __float2half_rn(x); }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return __float2bfloat16(x); }
+
+// bf16 / f16 bit helpers on raw 16-bit payloads
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+template <typename T> __device__ __forceinline__ float raw16_to_f32(unsigned short b);
+template <> __device__ __forceinline__ float raw16_to_f32<bf16_t>(unsigned short b) { return bf16_bits_to_f32(b); }
+template <> __device__ __forceinline__ float raw16_to_f32<f16_t>(unsigned short b) {
+    return __half2float(__ushort_as_half(b));
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+}  // namespace sfa

@@ -1,0 +1,350 @@
+// Single-query decode attention for gfx950: split-KV streaming kernel + reduce kernel.
+//
+// Replaces sink_attention/decode_kernel.py:28-113 (_decode_split_kv_kernel) and the
+// ~10-op PyTorch phase 2 at :201-226 of the reference.  The path is HBM-bound
+// (K and V are each read exactly once), so the design is about bytes in flight:
+//
+//   * one workgroup = (batch, KV head, KV split); ALL q heads of the GQA group are
+//     served from the same K/V registers (the reference re-reads K/V per q head);
+//   * a key row is spread over LPK lanes, 16 bytes per lane, so every wave load is a
+//     fully coalesced 1 KiB nontemporal read (K/V are read once: keep them out of L2);
+//   * each lane group keeps its own online-softmax state (m, l, acc) for U keys in
+//     flight; partial dot products are reduced over the LPK lanes with DPP row ops;
+//   * partial (m, l, o) per split go to the caller's workspace; the reduce kernel
+//     folds them and the s_aux "virtual split" (m = s_aux, l = 1, o = 0:
+//     decode_kernel.py:205-215) and writes q-dtype output.
+#include "sfa_common.hpp"
+#include "sfa_internal.hpp"
+
+namespace sfa {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the LPK consecutive lanes that hold one key row; every lane gets the total
+template <int LPK>
+__device__ __forceinline__ float group_sum(float x) {
+    if constexpr (LPK >= 2) x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+    if constexpr (LPK >= 4) x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    if constexpr (LPK >= 8) x += dpp_mov<0x141>(x);  // row_half_mirror
+    if constexpr (LPK >= 16) x += dpp_mov<0x140>(x); // row_mirror
+    if constexpr (LPK >= 32) x += __shfl_xor(x, 16, 64);
+    if constexpr (LPK >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+template <typename T, int EPL>
+__device__ __forceinline__ void cvt16B(const u32x4& raw, float (&f)[EPL]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(raw[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[2 * e] = raw16_to_f32<T>((unsigned short)(raw[e] & 0xffffu));
+            f[2 * e + 1] = raw16_to_f32<T>((unsigned short)(raw[e] >> 16));
+        }
+    }
+}
+
+template <typename T, int LPK, int GT>
+__global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View v, float* __restrict__ Mp,
+                                                          float* __restrict__ Lp, float* __restrict__ Op, int Hq,
+                                                          int Hkv, int Nkv, int D, int kps, int S, float scale) {
+    constexpr int EPL = 16 / sizeof(T);
+    constexpr int KPW = 64 / LPK;
+    constexpr int NSTREAM = 4 * KPW;
+    constexpr int U = (GT <= 1) ? 8 : 4;
+    constexpr int DP = LPK * EPL;  // padded head dim covered by a lane group
+
+    __shared__ float sm[4][GT];
+    __shared__ float sl[4][GT];
+    __shared__ float so[4][GT][DP];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = lane % LPK, kg = lane / LPK;
+    const bool dact = chunk * EPL < D;
+    const int d0 = dact ? chunk * EPL : 0;
+    const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+    const int g = Hq / Hkv;
+    const int k_beg = split * kps;
+    const int k_end = (k_beg + kps < Nkv) ? (k_beg + kps) : Nkv;
+    const int sid = wave * KPW + kg;
+
+    const T* kb = reinterpret_cast<const T*>(k.ptr) + (int64_t)b * k.sb + (int64_t)hk * k.sh + d0;
+    const T* vb = reinterpret_cast<const T*>(v.ptr) + (int64_t)b * v.sb + (int64_t)hk * v.sh + d0;
+
+    for (int h0 = 0; h0 < g; h0 += GT) {
+        float qf[GT][EPL];
+        float m[GT], l[GT], acc[GT][EPL];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int h = hk * g + h0 + t;
+            const T* qp = reinterpret_cast<const T*>(q.ptr) + (int64_t)b * q.sb + (int64_t)h * q.sh + d0;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp);
+            cvt16B<T, EPL>(raw, qf[t]);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                qf[t][e] = dact ? qf[t][e] * scale : 0.f;
+                acc[t][e] = 0.f;
+            }
+            m[t] = -INFINITY;
+            l[t] = 0.f;
+        }
+
+        for (int base = k_beg; base < k_end; base += NSTREAM * U) {
+            float kf[U][EPL], vf[U][EPL];
+            bool valid[U];
+            u32x4 kraw[U], vraw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = base + u * NSTREAM + sid;
+                valid[u] = kk < k_end;
+                const int kc = valid[u] ? kk : (k_end - 1);
+                kraw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (int64_t)kc * k.sn));
+                vraw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)kc * v.sn));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cvt16B<T, EPL>(kraw[u], kf[u]);
+                cvt16B<T, EPL>(vraw[u], vf[u]);
+            }
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                float s[U];
+                float bm = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) d = fmaf(qf[t][e], kf[u][e], d);
+                    d = group_sum<LPK>(d);
+                    s[u] = valid[u] ? d : -INFINITY;
+                    bm = fmaxf(bm, s[u]);
+                }
+                const float m_new = fmaxf(m[t], bm);
+                if (m_new > -INFINITY) {
+                    const float alpha = __expf(m[t] - m_new);  // exp(-inf) = 0 for the first keys
+                    float lt = l[t] * alpha;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc[t][e] *= alpha;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float pu = __expf(s[u] - m_new);
+                        lt += pu;
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) acc[t][e] = fmaf(pu, vf[u][e], acc[t][e]);
+                    }
+                    l[t] = lt;
+                    m[t] = m_new;
+                }
+            }
+        }
+
+        // merge the KPW key groups of the wave
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+#pragma unroll
+            for (int off = LPK; off < 64; off <<= 1) {
+                const float mo = __shfl_xor(m[t], off, 64);
+                const float lo = __shfl_xor(l[t], off, 64);
+                const float mn = fmaxf(m[t], mo);
+                const float a = (m[t] == -INFINITY) ? 0.f : __expf(m[t] - mn);
+                const float c = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+                l[t] = l[t] * a + lo * c;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const float ao = __shfl_xor(acc[t][e], off, 64);
+                    acc[t][e] = acc[t][e] * a + ao * c;
+                }
+                m[t] = mn;
+            }
+            if (kg == 0) {
+                if (chunk == 0) {
+                    sm[wave][t] = m[t];
+                    sl[wave][t] = l[t];
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) so[wave][t][chunk * EPL + e] = acc[t][e];
+            }
+        }
+        __syncthreads();
+        // merge the 4 waves and write the split's partial
+        if (wave == 0 && kg == 0) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                float mn = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sm[w][t]);
+                float lt = 0.f, o[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float a = (sm[w][t] == -INFINITY) ? 0.f : __expf(sm[w][t] - mn);
+                    lt += sl[w][t] * a;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) o[e] += so[w][t][chunk * EPL + e] * a;
+                }
+                const int h = hk * g + h0 + t;
+                const int64_t pidx = ((int64_t)b * Hq + h) * S + split;
+                if (chunk == 0) {
+                    Mp[pidx] = mn;
+                    Lp[pidx] = lt;
+                }
+                if (dact) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) Op[pidx * D + chunk * EPL + e] = o[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Fold the split partials and the s_aux virtual split (decode_kernel.py:205-226).
+template <typename T>
+__global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restrict__ Mp, const float* __restrict__ Lp,
+                                                           const float* __restrict__ Op,
+                                                           const float* __restrict__ s_aux, View o, int Hq, int S,
+                                                           int D) {
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int64_t base = ((int64_t)b * Hq + h) * S;
+    const float sa = s_aux ? s_aux[h] : -INFINITY;
+    float mstar = sa;
+    for (int s = 0; s < S; ++s) mstar = fmaxf(mstar, Mp[base + s]);
+    float L = (sa == -INFINITY) ? 0.f : __expf(sa - mstar);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float ms = Mp[base + s];
+        const float a = (ms == -INFINITY) ? 0.f : __expf(ms - mstar);
+        L += Lp[base + s] * a;
+        const float* op = Op + (base + s) * D;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int d = threadIdx.x + 128 * t;
+            if (d < D) acc[t] = fmaf(op[d], a, acc[t]);
+        }
+    }
+    L = fmaxf(L, 1e-8f);  // clamp(min=1e-8), decode_kernel.py:222
+    T* orow = reinterpret_cast<T*>(o.ptr) + (int64_t)b * o.sb + (int64_t)h * o.sh;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int d = threadIdx.x + 128 * t;
+        if (d < D) orow[d] = from_f32<T>(acc[t] / L);
+    }
+}
+
+template <typename T, int LPK>
+int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, float* Mp, float* Lp, float* Op,
+                 int Hq, int Hkv, int Nkv, int D, int kps, int S, float scale) {
+    switch (gt) {
+        case 8:
+            decode_split_kernel<T, LPK, 8><<<grid, 256, 0, stream>>>(q, k, v, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            break;
+        case 4:
+            decode_split_kernel<T, LPK, 4><<<grid, 256, 0, stream>>>(q, k, v, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            break;
+        default:
+            decode_split_kernel<T, LPK, 1><<<grid, 256, 0, stream>>>(q, k, v, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            break;
+    }
+    return launch_status("decode_split");
+}
+
+template <typename T>
+int launch_split_lpk(const DecodePlan& pl, dim3 grid, hipStream_t stream, View q, View k, View v, float* Mp,
+                     float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, float scale) {
+#define SFA_LPK_CASE(L)                                                                                          \
+    case L:                                                                                                      \
+        return launch_split<T, L>(pl.gt, grid, stream, q, k, v, Mp, Lp, Op, Hq, Hkv, Nkv, D, pl.keys_per_split, \
+                                  pl.splits, scale);
+    switch (pl.lpk) {
+        SFA_LPK_CASE(2)
+        SFA_LPK_CASE(4)
+        SFA_LPK_CASE(8)
+        SFA_LPK_CASE(16)
+        SFA_LPK_CASE(32)
+        SFA_LPK_CASE(64)
+    }
+#undef SFA_LPK_CASE
+    set_error("decode: bad lanes-per-key %d", pl.lpk);
+    return SFA_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype, DecodePlan* plan) {
+    const int es = dtype_size(dtype);
+    const int64_t row_bytes = D * es;
+    if (D <= 0 || row_bytes % 16 != 0 || row_bytes > 1024) {
+        set_error("decode: head dim %lld (%lld bytes/row) must be a multiple of 16 bytes and <= 1024 bytes",
+                  (long long)D, (long long)row_bytes);
+        return SFA_ERR_UNSUPPORTED;
+    }
+    if (Hkv <= 0 || Hq % Hkv != 0) {
+        set_error("decode: H_q (%lld) must be divisible by H_kv (%lld)", (long long)Hq, (long long)Hkv);
+        return SFA_ERR_INVALID_ARGUMENT;
+    }
+    const int chunks = (int)(row_bytes / 16);
+    int lpk = 2;
+    while (lpk < chunks) lpk <<= 1;
+    const int64_t g = Hq / Hkv;
+    const int gt = (g % 8 == 0) ? 8 : (g % 4 == 0) ? 4 : 1;
+    const int U = gt <= 1 ? 8 : 4;
+    const int iter_keys = 4 * (64 / lpk) * U;
+    const int64_t target_wgs = 2048;
+    const int64_t base = B * Hkv > 0 ? B * Hkv : 1;
+    int64_t want = cdiv64(target_wgs, base);
+    const int64_t min_keys = iter_keys > 256 ? iter_keys : 256;
+    int64_t max_splits = cdiv64(Nkv, min_keys);
+    if (max_splits < 1) max_splits = 1;
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    int64_t kps = cdiv64(cdiv64(Nkv > 0 ? Nkv : 1, want), iter_keys) * iter_keys;
+    int64_t splits = cdiv64(Nkv > 0 ? Nkv : 1, kps);
+    plan->splits = (int)splits;
+    plan->keys_per_split = (int)kps;
+    plan->lpk = lpk;
+    plan->gt = gt;
+    return SFA_OK;
+}
+
+int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+                  const float* s_aux, void* workspace, float scale, const DecodePlan& pl, hipStream_t stream) {
+    const int B = (int)q->shape[0], Hq = (int)q->shape[1], D = (int)q->shape[3];
+    const int Hkv = (int)k->shape[1], Nkv = (int)k->shape[2];
+    const int S = pl.splits;
+    float* Mp = reinterpret_cast<float*>(workspace);
+    float* Lp = Mp + (int64_t)B * Hq * S;
+    float* Op = Lp + (int64_t)B * Hq * S;
+    dim3 grid(S, Hkv, B);
+    int st;
+    if (q->dtype == SFA_DTYPE_F32)
+        st = launch_split_lpk<float>(pl, grid, stream, make_view(q), make_view(k), make_view(v), Mp, Lp, Op, Hq, Hkv,
+                                     Nkv, D, scale);
+    else if (q->dtype == SFA_DTYPE_F16)
+        st = launch_split_lpk<f16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), Mp, Lp, Op, Hq, Hkv,
+                                     Nkv, D, scale);
+    else
+        st = launch_split_lpk<bf16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), Mp, Lp, Op, Hq,
+                                      Hkv, Nkv, D, scale);
+    if (st != SFA_OK) return st;
+    dim3 rgrid(Hq, B);
+    if (q->dtype == SFA_DTYPE_F32)
+        decode_reduce_kernel<float><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
+    else if (q->dtype == SFA_DTYPE_F16)
+        decode_reduce_kernel<f16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
+    else
+        decode_reduce_kernel<bf16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
+    set_path("decode_splitkv_lpk%d_gt%d_s%d", pl.lpk, pl.gt, S);
+    return launch_status("decode_reduce");
+}
+
+}  // namespace sfa

@@ -1,0 +1,40 @@
+// Internal launcher declarations shared between the translation units of libsfa.
+#pragma once
+#include "sfa_common.hpp"
+
+namespace sfa {
+
+// sfa_generic.hip
+int fwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
+                const float* s_aux, const Problem& p, hipStream_t stream);
+int bwd_preprocess(const sfa_tensor* o, const sfa_tensor* d_o, const float* lse, const float* s_aux, float* delta,
+                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream);
+int64_t bwd_preprocess_nblk(int64_t N);
+int bwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
+                const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,
+                const sfa_tensor* dv, const Problem& p, hipStream_t stream);
+
+// sfa_fwd_mfma.hip
+bool fwd_mfma_supported(int dtype, int D);
+int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
+             const float* s_aux, const Problem& p, hipStream_t stream);
+
+// sfa_bwd_mfma.hip
+bool bwd_mfma_supported(int dtype, int D);
+size_t bwd_mfma_workspace_bytes(const Problem& p, int dtype);
+int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
+             const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,
+             const sfa_tensor* dv, void* workspace, const Problem& p, hipStream_t stream);
+
+// sfa_decode.hip
+struct DecodePlan {
+    int splits;          // KV splits per (batch, kv head)
+    int keys_per_split;  // multiple of the keys one workgroup iteration covers
+    int lpk;             // lanes per key row (power of two)
+    int gt;              // q heads of a GQA group processed per pass
+};
+int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype, DecodePlan* plan);
+int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+                  const float* s_aux, void* workspace, float scale, const DecodePlan& plan, hipStream_t stream);
+
+}  // namespace sfa

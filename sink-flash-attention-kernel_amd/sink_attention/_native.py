@@ -1,0 +1,117 @@
+"""ctypes binding of libsfa.so (C ABI in include/sfa.h).
+
+The shared library holds the hand-written gfx950 HIP kernels.  There is NO
+fallback: if the library is missing or a call fails, this module raises.
+Build it with ``make -C sink-flash-attention-kernel_amd`` (or
+``python -c "import __graft_entry__ as g; g.build()"`` from the repo root).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfa.so")
+
+SFA_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+FLAG_FORCE_GENERIC = 0x1
+ABI_VERSION = 1
+
+
+class SfaTensor(ctypes.Structure):
+    _fields_ = [
+        ("ptr", ctypes.c_void_p),
+        ("shape", ctypes.c_int64 * 4),
+        ("stride", ctypes.c_int64 * 4),
+        ("dtype", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _bind(lib):
+    P = ctypes.POINTER(SfaTensor)
+    vp, i32, u32, f32, sz, i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_size_t,
+                                   ctypes.c_int64)
+    lib.sfa_abi_version.restype = i32
+    lib.sfa_abi_version.argtypes = []
+    lib.sfa_last_error.restype = ctypes.c_char_p
+    lib.sfa_last_error.argtypes = []
+    lib.sfa_last_path.restype = ctypes.c_char_p
+    lib.sfa_last_path.argtypes = []
+    lib.sfa_fwd.restype = i32
+    lib.sfa_fwd.argtypes = [P, P, P, P, vp, vp, i32, i32, f32, u32, vp]
+    lib.sfa_bwd_workspace_bytes.restype = sz
+    lib.sfa_bwd_workspace_bytes.argtypes = [i64, i64, i64, i64, i64, i32, i32, i32, u32]
+    lib.sfa_bwd.restype = i32
+    lib.sfa_bwd.argtypes = [P, P, P, P, P, vp, vp, P, P, P, vp, vp, sz, i32, i32, f32, u32, vp]
+    lib.sfa_decode_workspace_bytes.restype = sz
+    lib.sfa_decode_workspace_bytes.argtypes = [i64, i64, i64, i64, i64, i32]
+    lib.sfa_decode.restype = i32
+    lib.sfa_decode.argtypes = [P, P, P, P, vp, vp, sz, f32, u32, vp]
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if libsfa.so is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"sink_attention: {LIB_PATH} not found. The HIP extension is required (there is no "
+                        "Python/CPU fallback). Build it with `make -C sink-flash-attention-kernel_amd`.")
+                handle = ctypes.CDLL(LIB_PATH)
+                _bind(handle)
+                v = handle.sfa_abi_version()
+                if v != ABI_VERSION:
+                    raise RuntimeError(f"libsfa.so ABI version {v}, expected {ABI_VERSION}: rebuild the extension")
+                _lib = handle
+    return _lib
+
+
+def last_path() -> str:
+    return lib().sfa_last_path().decode()
+
+
+def desc(t: torch.Tensor) -> SfaTensor:
+    """Describe a 4-D [B,H,N,D] tensor (any B/H/N strides, unit D stride)."""
+    d = SfaTensor()
+    d.ptr = t.data_ptr()
+    for i in range(4):
+        d.shape[i] = t.shape[i]
+        d.stride[i] = t.stride(i)
+    d.dtype = SFA_DTYPE[t.dtype]
+    d.reserved = 0
+    return d
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = lib().sfa_last_error().decode()
+        kind = "argument/support error" if status < 0 else "HIP error"
+        raise RuntimeError(f"{what} failed ({kind} {status}): {msg}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "sink_attention runs only on MI355X (HIP) tensors; got a CPU tensor and there is no CPU fallback")
+
+
+def unit_inner(t: torch.Tensor) -> torch.Tensor:
+    """Kernels take arbitrary B/H/N strides but need the head dim contiguous."""
+    if t.stride(-1) != 1 and t.shape[-1] > 1:
+        return t.contiguous()
+    return t
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

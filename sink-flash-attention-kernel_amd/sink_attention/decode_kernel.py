@@ -1,0 +1,54 @@
+"""sink_decode_attention: single-query (decode) attention with s_aux, MI355X / HIP.
+
+Same public contract as the reference's ``sink_attention/decode_kernel.py:120-226``:
+q [B,H_q,1,D] against every key handed in (no mask: windowing is the cache's job),
+optional ``s_aux`` [H_q] folded in as a virtual KV split (m = s_aux, l = 1, o = 0).
+Both phases (split-KV streaming and the reduction, which the reference does in
+~10 PyTorch ops) are HIP kernels behind ``sfa_decode`` (include/sfa.h).
+The head dim no longer has to be a power of two; a K/V row must be a multiple of 16 bytes.
+"""
+import math
+
+import torch
+
+from . import _native as N
+
+
+def sink_decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                          s_aux: torch.Tensor = None) -> torch.Tensor:
+    N.require_gpu(q, k, v, s_aux)
+    B, H_q, N_q, D = q.shape
+    H_kv = k.shape[1]
+    N_kv = k.shape[2]
+    assert N_q == 1, f"sink_decode_attention requires N_q=1, got {N_q}"
+    assert H_q % H_kv == 0, f"H_q ({H_q}) must be divisible by H_kv ({H_kv})"
+    assert k.shape == (B, H_kv, N_kv, D) and v.shape == k.shape, "k/v must be [B, H_kv, N_kv, D]"
+    if q.dtype not in N.SFA_DTYPE or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError(f"q/k/v must share one dtype in (float32, float16, bfloat16); got "
+                        f"{q.dtype}, {k.dtype}, {v.dtype}")
+    row_bytes = D * q.element_size()
+    assert row_bytes % 16 == 0 and row_bytes <= 1024, f"D={D}: a K/V row must be a multiple of 16 bytes, <= 1 KiB"
+    scale = 1.0 / math.sqrt(D)
+
+    def rows16(t):
+        t = N.unit_inner(t)
+        es = t.element_size()
+        if t.data_ptr() % 16 or any((t.stride(i) * es) % 16 for i in range(3)):
+            t = t.contiguous()
+        return t
+
+    q, k, v = rows16(q.detach()), rows16(k.detach()), rows16(v.detach())
+    s_aux_f = None
+    if s_aux is not None:
+        assert s_aux.shape == (H_q,), f"s_aux shape must be [H_q={H_q}], got {s_aux.shape}"
+        s_aux_f = s_aux.detach().contiguous().float()
+    out = torch.empty((B, H_q, 1, D), device=q.device, dtype=q.dtype)
+    lib = N.lib()
+    ws_bytes = lib.sfa_decode_workspace_bytes(B, H_q, H_kv, N_kv, D, N.SFA_DTYPE[q.dtype])
+    ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)
+    with torch.cuda.device(q.device):
+        st = lib.sfa_decode(N.desc(q), N.desc(k), N.desc(v), N.desc(out),
+                            s_aux_f.data_ptr() if s_aux_f is not None else None, ws.data_ptr(), ws.numel(),
+                            scale, 0, N.stream_ptr(q.device))
+    N.check(st, "sfa_decode")
+    return out

