@@ -67,8 +67,9 @@ int sfa_abi_version(void);
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char* sfa_last_error(void);
 
-/* Thread-local name of the kernel family the last successful call on this thread
- * dispatched to, e.g. "fwd_mfma_bf16_d128", "fwd_generic_f32".  For tests/benchmarks. */
+/* Name of the kernel family the last successful call in this PROCESS dispatched to (any
+ * thread: autograd runs backward on its own thread), e.g. "fwd_mfma_bf16_d128_nw8_hpw4",
+ * "bwd_generic_f32math".  Diagnostic for tests/benchmarks only; racy by design. */
 const char* sfa_last_path(void);
 
 /*

@@ -9,7 +9,7 @@
 namespace sfa {
 
 static thread_local char g_err[512] = "";
-static thread_local char g_path[128] = "";
+static char g_path[128] = "";  // diagnostic only: last kernel family dispatched in this process (any thread)
 
 void set_error(const char* fmt, ...) {
     va_list ap;

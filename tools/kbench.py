@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench (exploration tool, not the contract bench): times sink_flash_attention fwd / fwd+bwd and
+sink_decode_attention at the BASELINE.json configs with HIP events on torch's current stream.
+usage: python tools/kbench.py [fwd] [bwd] [decode] [--cfg C2,C3,C4] [--iters 20]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "sink-flash-attention-kernel_amd"), ROOT]
+import torch
+
+from oracle.sink_oracle import pair_count_closed
+from sink_attention import _native, sink_decode_attention, sink_flash_attention
+
+CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
+    "C2": (4, 32, 32, 4096, 128, 4, 1024, False),
+    "C3": (4, 32, 8, 8192, 128, 4, 4096, False),
+    "C3mha": (4, 32, 32, 8192, 128, 4, 4096, False),
+    "C4": (1, 64, 8, 8192, 80, 0, 128, True),
+    "C4b4": (4, 64, 8, 8192, 80, 0, 128, True),
+    "D64": (4, 32, 8, 8192, 64, 4, 4096, False),
+    "causal": (4, 32, 8, 8192, 128, 0, 8192, False),
+}
+
+
+def timeit(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["fwd"])
+    ap.add_argument("--cfg", default="C2,C3,C4")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
+    dev = "cuda"
+    for name in args.cfg.split(","):
+        if not name:
+            continue
+        B, Hq, Hkv, N, D, ns, W, aux = CFG[name]
+        torch.manual_seed(42)
+        q = torch.randn(B, Hq, N, D, device=dev, dtype=dt)
+        k = torch.randn(B, Hkv, N, D, device=dev, dtype=dt)
+        v = torch.randn(B, Hkv, N, D, device=dev, dtype=dt)
+        sa = (torch.randn(Hq, device=dev) * 0.5) if aux else None
+        pairs = pair_count_closed(N, ns, W)
+        f_fwd = 4 * D * pairs * B * Hq
+        if "fwd" in args.what:
+            med, mn = timeit(lambda: sink_flash_attention(q, k, v, ns, W, sa), args.iters)
+            io = (2 * q.numel() + 2 * k.numel()) * 2
+            print(f"{name} fwd  {_native.last_path():34s} med {med:8.3f} ms  min {mn:8.3f} ms  "
+                  f"{f_fwd / med / 1e9:8.1f} TFLOP/s ({f_fwd / med / 1e9 / 2516.6 * 100:5.1f}% peak)  "
+                  f"min-IO {io / med / 1e6:7.1f} GB/s", flush=True)
+        if "bwd" in args.what:
+            qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+            sag = sa.clone().requires_grad_(True) if aux else None
+            do = torch.randn_like(q)
+
+            def step():
+                o = sink_flash_attention(qg, kg, vg, ns, W, sag)
+                o.backward(do)
+                qg.grad = kg.grad = vg.grad = None
+            med, mn = timeit(step, args.iters)
+            f = 3.5 * f_fwd
+            print(f"{name} f+b  {_native.last_path():34s} med {med:8.3f} ms  min {mn:8.3f} ms  "
+                  f"{f / med / 1e9:8.1f} TFLOP/s ({f / med / 1e9 / 2516.6 * 100:5.1f}% peak)", flush=True)
+    if "decode" in args.what:
+        for (B, Hq, Hkv, Nkv, D) in [(32, 32, 32, 131072, 128), (32, 32, 32, 4100, 128), (32, 32, 8, 131072, 128),
+                                     (1, 32, 8, 4100, 128), (1, 64, 8, 4100, 128)]:
+            q = torch.randn(B, Hq, 1, D, device=dev, dtype=dt)
+            k = torch.randn(B, Hkv, Nkv, D, device=dev, dtype=dt)
+            v = torch.randn(B, Hkv, Nkv, D, device=dev, dtype=dt)
+            med, mn = timeit(lambda: sink_decode_attention(q, k, v), args.iters)
+            byts = 2 * k.numel() * 2 + 2 * q.numel() * 2
+            print(f"decode B{B} Hq{Hq} Hkv{Hkv} N{Nkv} {_native.last_path():28s} med {med:8.4f} ms min {mn:8.4f} ms "
+                  f"{byts / med / 1e6:8.1f} GB/s ({byts / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
+            del q, k, v
+
+
+if __name__ == "__main__":
+    main()
