@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Contract benchmark: sink flash attention fwd+bwd at BASELINE.json's metric shape on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload ("C3", BASELINE.json configs[2], the shape the metric is quoted on):
+    bf16, B=4 per GPU, H_q=32, H_kv=8, N=8192, D=128, num_sink=4, window=4096, synthetic randn inputs.
+A step = one forward + one backward of sink_flash_attention through the product op (C ABI -> HIP kernels) with
+inputs resident in HBM.  (batch, KV head) units are independent, so ranks just own disjoint batches: no
+data-path collective, weak scaling, value = all ranks' algorithmic FLOPs / max-over-ranks time.
+
+Algorithmic FLOPs: fwd+bwd = 14 * D * pairs(N, ns, W) * B * H_q; masked-out work,
+recomputation and padding do not count.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel of the step (the longest of: forward kernel, backward dK/dV kernel, backward dQ
+                kernel), its algorithmic FLOPs / its average duration measured with HIP events on the launching
+                stream inside the timed steps (sfa_debug_set_stage_events for the backward stages), against the
+                gfx950 dense bf16 MFMA peak 2516.6 TFLOP/s.  traffic: HBM bytes per launch from the committed
+                rocprofv3 PMC run (profiles/*_pmc.json) if present, else null.
+  cpu_baseline  the reference's eager fp32 algorithm (oracle/sink_oracle.py restatement, dense N x N, torch on all
+                host cores) timed on a bounded slice of the same workload (1 batch element x 1 KV group = 4 q heads),
+                rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "sink-flash-attention-kernel_amd"), ROOT]
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md, matrix cores)
+WORKLOAD = dict(name="C3", B=4, Hq=32, Hkv=8, N=8192, D=128, ns=4, W=4096)
+
+
+class HipEvents:
+    """Raw hipEvent_t handles (the library records them on its launch stream)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.ev = (ctypes.c_void_p * n)()
+        for i in range(n):
+            e = ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+            self.ev[i] = e
+
+    def elapsed(self, i, j):
+        ms = ctypes.c_float()
+        self.hip.hipEventSynchronize(self.ev[j])
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), self.ev[i], self.ev[j])
+        return ms.value if rc == 0 else float("nan")
+
+
+def cpu_baseline(w):
+    """Dense eager fp32 attention fwd+bwd on host cores for 1 batch x 1 KV group of the workload."""
+    from oracle import sink_oracle as O
+    g = w["Hq"] // w["Hkv"]
+    N, D = w["N"], w["D"]
+    torch.set_num_threads(os.cpu_count())
+    gen = torch.Generator().manual_seed(1)
+    q = torch.randn(1, g, N, D, generator=gen).requires_grad_(True)
+    k = torch.randn(1, 1, N, D, generator=gen).requires_grad_(True)
+    v = torch.randn(1, 1, N, D, generator=gen).requires_grad_(True)
+    do = torch.randn(1, g, N, D, generator=gen)
+    t0 = time.perf_counter()
+    o, _ = O.sink_attention_dense(q, k, v, w["ns"], w["W"], dtype=torch.float32)
+    o.backward(do)
+    dt = time.perf_counter() - t0
+    flops = O.flops_fwd_bwd(1, g, N, D, w["ns"], w["W"])
+    return {"value": round(flops / dt / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"dense eager fp32 fwd+bwd of 1 batch x 1 KV group ({g} q heads) at N={N} D={D} ns={w['ns']} "
+                      f"W={w['W']}: {dt:.2f} s; per-(batch, KV head) work is independent, so the full workload is "
+                      f"{w['B'] * w['Hkv']}x this"}
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, if any."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(path))
+            if kernel_key in d:
+                best = d[kernel_key].get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from oracle.sink_oracle import flops_fwd, flops_fwd_bwd
+    from sink_attention import _native, sink_flash_attention
+
+    w = WORKLOAD
+    B, Hq, Hkv, N, D, ns, W = (w[x] for x in ("B", "Hq", "Hkv", "N", "D", "ns", "W"))
+    torch.manual_seed(42 + rank)
+    q = torch.randn(B, Hq, N, D, device=dev, dtype=torch.bfloat16).requires_grad_(True)
+    k = torch.randn(B, Hkv, N, D, device=dev, dtype=torch.bfloat16).requires_grad_(True)
+    v = torch.randn(B, Hkv, N, D, device=dev, dtype=torch.bfloat16).requires_grad_(True)
+    do = torch.randn(B, Hq, N, D, device=dev, dtype=torch.bfloat16)
+
+    lib = _native.lib()
+    stage = HipEvents(4)
+    fwd_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    paths = {}
+
+    def step(i=None):
+        if i is not None:
+            fwd_ev[i][0].record()
+        out = sink_flash_attention(q, k, v, num_sink=ns, window_size=W)
+        if i is not None:
+            fwd_ev[i][1].record()
+        paths["fwd"] = _native.last_path()
+        out.backward(do)
+        q.grad = k.grad = v.grad = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    paths["bwd"] = _native.last_path()
+    stage_ms = {"pre": [], "dkdv": [], "dq": []}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = i == args.steps - 1
+        if last:      # stage events are armed for the final timed step only (one extra hipEventRecord x4)
+            lib.sfa_debug_set_stage_events(stage.ev, 4)
+        step(i)
+        if last:
+            torch.cuda.synchronize()
+            lib.sfa_debug_set_stage_events(None, 0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    ms_per_step = dt / args.steps * 1e3
+    f_fb = flops_fwd_bwd(B, Hq, N, D, ns, W)
+    f_f = flops_fwd(B, Hq, N, D, ns, W)
+    value = f_fb * world / (dt / args.steps) / 1e12
+
+    if rank == 0:
+        fwd_ms = sorted(s.elapsed_time(e) for s, e in fwd_ev)
+        fwd_avg = sum(fwd_ms) / len(fwd_ms)
+        pre, dkdv, dq = stage.elapsed(0, 1), stage.elapsed(1, 2), stage.elapsed(2, 3)
+        # algorithmic FLOPs per kernel: fwd 4, dK/dV kernel 4 (dV, dK) + its share ... -> use the 5-product split:
+        # S and dP recomputations are not algorithmic work; dK/dV kernel owns dV+dK (4*D*pairs) plus S,dP (4) = 8,
+        # dQ kernel owns dQ (2*D*pairs).  The two backward kernels together carry the 10*D*pairs of the backward.
+        kernels = {
+            "fwd": (fwd_avg, f_f, paths.get("fwd", "")),
+            "bwd_dkdv": (dkdv, f_f * 2.0, paths.get("bwd", "")),
+            "bwd_dq": (dq, f_f * 0.5, paths.get("bwd", "")),
+        }
+        dom = max(kernels, key=lambda n: kernels[n][0] if kernels[n][0] == kernels[n][0] else -1)
+        dur, fl, path = kernels[dom]
+        achieved = fl / (dur * 1e-3) / 1e12 if dur and dur == dur and dur > 0 else None
+        roofline = {"bound": "mfma", "kernel": f"{dom} ({path})",
+                    "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
+                    "avg_launch_ms": round(dur, 4), "traffic": pmc_traffic(dom),
+                    "stage_ms": {"fwd": round(fwd_avg, 4), "bwd_preprocess": round(pre, 4),
+                                 "bwd_dkdv": round(dkdv, 4), "bwd_dq": round(dq, 4)}}
+        line = {
+            "metric": "attn fwd+bwd TFLOP/s (% MFMA peak) at B=4 H=32 N=8192 D=128 bf16",
+            "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "pct_mfma_peak": round(value / world / PEAK_BF16_TFLOPS * 100, 2),
+            "config": {"workload": "C3: sink_flash_attention fwd+bwd, GQA bf16, B=4 per GPU, H_q=32, H_kv=8, "
+                                   "N=8192, D=128, num_sink=4, window=4096", "batch_per_gpu": B,
+                       "global_batch": B * world, "seq_len": N, "parallelism": f"independent batches x{world}",
+                       "algorithmic_gflop_per_step_per_gpu": round(f_fb / 1e9, 1)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,15 @@ const char* sfa_last_error(void);
 const char* sfa_last_path(void);
 
 /*
+ * Measurement hook (bench.py): arm `count` caller-created hipEvent_t handles (null entries are
+ * skipped; count = 0 disarms).  While armed, sfa_bwd records on its stream
+ *   events[0] at entry, [1] after the preprocess kernels (Delta, ds_aux),
+ *   [2] after the dK/dV kernel, [3] after the dQ kernel (= end of sfa_bwd).
+ * Process-global and not thread-safe by design: a diagnostic, never used by the op itself.
+ */
+int sfa_debug_set_stage_events(void* const* events, int count);
+
+/*
  * Forward.  valid(i,j) = (j <= i) && (j < num_sink || j >= i - window + 1)
  *   q,o  [B, Hq, N, D]     k,v [B, Hkv, N, D]   Hq % Hkv == 0
  *   lse  [B, Hq, N] float32, contiguous: log-sum-exp of the scaled scores of the row

@@ -11,6 +11,13 @@ namespace sfa {
 static thread_local char g_err[512] = "";
 static char g_path[128] = "";  // diagnostic only: last kernel family dispatched in this process (any thread)
 
+// measurement hook (sfa_debug_set_stage_events): process-global on purpose, the autograd thread runs sfa_bwd
+static void* const* g_stage_events = nullptr;
+static int g_stage_count = 0;
+void record_stage(int i, hipStream_t stream) {
+    if (g_stage_events && i < g_stage_count && g_stage_events[i]) (void)hipEventRecord((hipEvent_t)g_stage_events[i], stream);
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -105,6 +112,11 @@ extern "C" {
 int sfa_abi_version(void) { return SFA_ABI_VERSION; }
 const char* sfa_last_error(void) { return g_err; }
 const char* sfa_last_path(void) { return g_path; }
+int sfa_debug_set_stage_events(void* const* events, int count) {
+    g_stage_events = count > 0 ? events : nullptr;
+    g_stage_count = count > 0 ? count : 0;
+    return SFA_OK;
+}
 
 int sfa_fwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
             const float* s_aux, int num_sink, int window, float scale, unsigned flags, void* stream) {
@@ -156,10 +168,16 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     hipStream_t s = (hipStream_t)stream;
     float* delta = reinterpret_cast<float*>((char*)workspace + w.delta_off);
     float* dsaux_part = reinterpret_cast<float*>((char*)workspace + w.dsaux_off);
+    record_stage(0, s);
     st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s);
+    record_stage(1, s);
     if (st) return st;
-    if (use_mfma) return bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, s);
-    return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, s);
+    if (use_mfma)
+        st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, s);
+    else
+        st = bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, s);
+    record_stage(3, s);
+    return st;
 }
 
 size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype) {

@@ -16,6 +16,7 @@ namespace sfa {
 // ---------------------------------------------------------------- host side
 void set_error(const char* fmt, ...);
 void set_path(const char* fmt, ...);
+void record_stage(int i, hipStream_t stream);  // no-op unless sfa_debug_set_stage_events() armed it
 
 #define SFA_CHECK_ARG(cond, ...)             \
     do {                                     \

@@ -417,12 +417,14 @@ int bwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, c
                 bwd_dkdv_generic_kernel<T, DSLOTS, 4><<<grid_k, block, 0, stream>>>(
                     make_view(q), make_view(k), make_view(v), make_view(d_o), make_view(dk), make_view(dv), lse,
                     delta, p);
+                record_stage(2, stream);
                 bwd_dq_generic_kernel<T, DSLOTS, 4><<<grid_q, block, 0, stream>>>(
                     make_view(q), make_view(k), make_view(v), make_view(d_o), make_view(dq), lse, delta, p);
             } else {
                 bwd_dkdv_generic_kernel<T, DSLOTS, 1><<<grid_k, block, 0, stream>>>(
                     make_view(q), make_view(k), make_view(v), make_view(d_o), make_view(dk), make_view(dv), lse,
                     delta, p);
+                record_stage(2, stream);
                 bwd_dq_generic_kernel<T, DSLOTS, 1><<<grid_q, block, 0, stream>>>(
                     make_view(q), make_view(k), make_view(v), make_view(d_o), make_view(dq), lse, delta, p);
             }

@@ -45,6 +45,8 @@ def _bind(lib):
     lib.sfa_last_error.argtypes = []
     lib.sfa_last_path.restype = ctypes.c_char_p
     lib.sfa_last_path.argtypes = []
+    lib.sfa_debug_set_stage_events.restype = i32
+    lib.sfa_debug_set_stage_events.argtypes = [ctypes.POINTER(ctypes.c_void_p), i32]
     lib.sfa_fwd.restype = i32
     lib.sfa_fwd.argtypes = [P, P, P, P, vp, vp, i32, i32, f32, u32, vp]
     lib.sfa_bwd_workspace_bytes.restype = sz
