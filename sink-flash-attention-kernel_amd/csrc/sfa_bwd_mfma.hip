@@ -1,12 +1,616 @@
-// placeholder until the MFMA backward lands
+// MFMA backward for gfx950: sink + sliding-window flash attention.
+// Replaces _sink_flash_attn_bwd_dkdv_kernel (sink_attention/sink_flash_attention.py:256-364) and
+// _sink_flash_attn_bwd_dq_kernel (:371-484) of the reference plus its PyTorch GQA group sum (:648-651).
+// Two deterministic kernels (no atomics), both recompute P = exp(S*scale - LSE) from the forward's LSE:
+//
+//  dK/dV kernel (K-stationary).  A workgroup = 4 wavefronts = 256 keys of one (batch, KV head); each wave owns
+//    64 keys and keeps dK^T and dV^T of them in 256 accumulator registers (one wave per SIMD, 512-register waves)
+//    while the workgroup sweeps ALL q heads of the GQA group x the 32-row query slices that can see the block,
+//    so dK/dV are written once in [B,H_kv,N,D] (the reference writes per-Q-head copies and sums in PyTorch).
+//    S and dP are computed with the KEY on the MFMA lane (S = Q K^T, dP = dO V^T with Q/dO row fragments as the
+//    A operand); their accumulators, packed to 16 bit, are directly the B operands of dV^T += dO^T P and
+//    dK^T += Q^T dS (A operands from ds_read_b64_tr_b16 on the same LDS image of the Q / dO slice).  -LSE/scale
+//    and -Delta are loaded as the INITIAL accumulators of S and dP, so p = exp2(c * S') and dS = p * dP' need no
+//    row broadcast.  Sink keys (block 0) simply sweep every later query slice; block 0 is dispatched first.
+//
+//  dQ kernel (Q-stationary).  Same work decomposition as the forward (8 waves = HPW q heads x row blocks, K/V
+//    tile staged once per workgroup): S^T = K Q^T, dP^T = V dO^T with the query row on the lane, dS^T packed as
+//    the B operand of dQ^T += K^T dS^T (K^T fragments by transposed LDS reads of the K tile).
 #include "sfa_common.hpp"
 #include "sfa_internal.hpp"
+
 namespace sfa {
-bool bwd_mfma_supported(int, int) { return false; }
-size_t bwd_mfma_workspace_bytes(const Problem&, int) { return 0; }
-int bwd_mfma(const sfa_tensor*, const sfa_tensor*, const sfa_tensor*, const sfa_tensor*, const float*, const float*,
-             const sfa_tensor*, const sfa_tensor*, const sfa_tensor*, void*, const Problem&, hipStream_t) {
-    set_error("bwd_mfma not built");
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    using frag = bf16x8_t;
+    using elem = __bf16;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {
+    using frag = f16x8_t;
+    using elem = _Float16;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct BwdArgs {
+    View q, k, v, d_o, dq, dk, dv;
+    const float* lse;
+    const float* delta;
+    int B, Hq, Hkv, N;
+    int num_sink, window;  // window clamped to [0, N]
+    float scale, scale_log2;
+    unsigned q_range, k_range, v_range, do_range, dq_range, dk_range, dv_range;
+    int n_kblocks;               // dK/dV kernel: ceil(N / 128)
+    int hpw, rb, n_qtiles, hgroups;  // dQ kernel
+};
+
+// One LDS image serves row reads (ds_read_b128 MFMA operand) and transposed reads (ds_read_b64_tr_b16):
+// XOR the 16-byte chunk index with sw(row).  256-byte rows: 16 chunks; 128-byte rows (D <= 64): 8 chunks.
+template <int ROWB>
+__device__ __forceinline__ int sw(int row) {
+    if constexpr (ROWB == 256)
+        return ((row & 3) << 2) | ((row >> 2) & 3);
+    else
+        return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+template <typename frag>
+__device__ __forceinline__ frag tr_pair(const char* p, int rowb8) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + rowb8));
+    s16x8 vv;
+    vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+    vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+    return __builtin_bit_cast(frag, vv);
+}
+
+// ===================================================================== dK / dV
+constexpr int kKB = 128;   // keys per workgroup (32 per wave)
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    using E = typename M::elem;
+    constexpr int DK = D / 16;
+    constexpr int DVB = (D + 31) / 32;
+    constexpr int CPR = D / 8;
+    constexpr int ROWB = (D <= 64) ? 128 : 256;
+    constexpr int QT = 64;                       // query rows per iteration (two 32-row MFMA slices)
+    constexpr int TILE = QT * ROWB;              // bytes of one Q (or dO) slice image
+    constexpr int STAGE = 2 * TILE + 512;        // Q | dO | -lse/scale[64] | -delta[64]
+    constexpr int NCH = QT * CPR;                // 16-byte chunks per slice
+    constexpr int NLD = (NCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kb = bid % a.n_kblocks;
+    int rest = bid / a.n_kblocks;
+    const int hk = rest % a.Hkv;
+    const int b = rest / a.Hkv;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int N = a.N, W = a.window, ns = a.num_sink;
+    const int g = a.Hq / a.Hkv;
+    const int kb0 = kb * kKB;
+    const int kb1 = (kb0 + kKB < N) ? kb0 + kKB : N;
+    const int kw0 = kb0 + 32 * wave;   // wave's first key
+    const int key = kw0 + r;           // lane's key
+
+    const char* kbase = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
+    const char* vbase = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, a.k_range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, a.v_range, 0x00020000);
+
+    // ---- K and V fragments of the wave's 32 keys stay in registers: B operands of S = Q K^T, dP = dO V^T
+    frag kf[DK], vf[DK];
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+        const unsigned ko = (unsigned)key * (unsigned)(a.k.sn * 2) + (unsigned)((2 * ks + h) * 16);
+        const unsigned vo = (unsigned)key * (unsigned)(a.v.sn * 2) + (unsigned)((2 * ks + h) * 16);
+        kf[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rk, ko, 0, 0));
+        vf[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0));
+    }
+
+    // ---- iteration space: q heads of the group x 64-row slices that can see the block
+    int i_hi;
+    if (kb0 < ns) {
+        i_hi = N;
+    } else {
+        i_hi = kb1 - 1 + W;
+        if (i_hi > N) i_hi = N;
+    }
+    const int qt_lo = kb0 / QT;
+    int qt_hi = (i_hi + QT - 1) / QT;
+    if (qt_hi < qt_lo) qt_hi = qt_lo;
+    const int nq = qt_hi - qt_lo;
+    const int n_it = g * nq;
+
+    f32x16 dKt[DVB], dVt[DVB];
+#pragma unroll
+    for (int db = 0; db < DVB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dKt[db][i] = 0.f;
+            dVt[db][i] = 0.f;
+        }
+
+    u32x4 qst[NLD], dst[NLD];
+    float cst = 0.f;
+    auto issue_loads = [&](int it) {
+        const int hh = it / nq, qt = qt_lo + it % nq;
+        const int head = hk * g + hh;
+        const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
+        const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / CPR, ch = c % CPR;
+            const bool in = (NCH % 256 == 0) || (c < NCH);
+            const unsigned qo = in ? (unsigned)(qt * QT + row) * (unsigned)(a.q.sn * 2) + (unsigned)(ch * 16) : 0xFFFFFFF0u;
+            const unsigned oo = in ? (unsigned)(qt * QT + row) * (unsigned)(a.d_o.sn * 2) + (unsigned)(ch * 16) : 0xFFFFFFF0u;
+            qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, qo, 0, 0);
+            dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, oo, 0, 0);
+        }
+        if (tid < 128) {
+            const int row = qt * QT + (tid & 63);
+            const int64_t idx = ((int64_t)b * a.Hq + head) * N + row;
+            if (tid < 64)
+                cst = (row < N) ? -a.lse[idx] / a.scale : -INFINITY;   // rows >= N: p = exp2(c * -inf) = 0
+            else
+                cst = (row < N) ? -a.delta[idx] : 0.f;
+        }
+    };
+    auto write_lds = [&](int buf) {
+        char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / CPR, ch = c % CPR;
+            if ((NCH % 256 == 0) || (c < NCH)) {
+                const int o = row * ROWB + ((ch ^ sw<ROWB>(row)) << 4);
+                *reinterpret_cast<u32x4*>(st + o) = qst[i];
+                *reinterpret_cast<u32x4*>(st + TILE + o) = dst[i];
+            }
+        }
+        if (tid < 128) *reinterpret_cast<float*>(st + 2 * TILE + tid * 4) = cst;
+    };
+
+    // per-lane LDS addressing
+    const int rowrd = r * ROWB;                 // row read of slice row (32*sub + r): A operand of S / dP
+    const int rsw = sw<ROWB>(r);                // sw(32*sub + r) == sw(r)
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int tr_row = 4 * h + q4;              // + 32*sub + 16*s ; second read + 8
+    const int tr_col = 2 * g1 + (p4 >> 1);      // + 4*db
+    const int tr_byte = (p4 & 1) * 8;
+    const float c = a.scale_log2;
+
+    if (n_it > 0) {
+        issue_loads(0);
+        write_lds(0);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < n_it; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_it) issue_loads(it + 1);
+        const int q0 = (qt_lo + it % nq) * QT;
+        // wave-level classification of (32 keys) x (64 rows)
+        const bool needed = (kw0 < N) && (kw0 <= q0 + 63) && (kw0 < ns || kw0 + 31 + W > q0);
+        if (needed) {
+            const bool full = (kw0 + 31 <= q0) && (q0 + 63 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 63));
+            const char* st = smem + buf * STAGE;
+            const char* ql = st;
+            const char* dol = st + TILE;
+            const float* cl = reinterpret_cast<const float*>(st + 2 * TILE);
+            frag pP[2][2], pS[2][2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                // initial accumulators: S' = -LSE/scale + Q K^T, dP' = -Delta + dO V^T (row = query (i&3)+8(i>>2)+4h)
+                f32x16 S, dP;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + 32 * sub + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(cl + 64 + 32 * sub + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        S[4 * g4 + e] = l4[e];
+                        dP[4 * g4 + e] = d4[e];
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) {
+                    const int o = sub * 32 * ROWB + rowrd + (((2 * ks + h) ^ rsw) << 4);
+                    const frag qa = *reinterpret_cast<const frag*>(ql + o);
+                    const frag da = *reinterpret_cast<const frag*>(dol + o);
+                    S = M::run(qa, kf[ks], S);
+                    dP = M::run(da, vf[ks], dP);
+                }
+                // P = exp2(c * S'), dS = P * dP'  -> packed B operands (k index = query row, permuted)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float p = __builtin_amdgcn_exp2f(c * S[i]);
+                    if (!full) {
+                        const int qi = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const bool valid = (key <= qi) && (key < ns || key + W > qi) && (qi < N);
+                        p = valid ? p : 0.f;
+                    }
+                    pP[sub][i >> 3][i & 7] = (E)p;
+                    pS[sub][i >> 3][i & 7] = (E)(p * dP[i]);
+                }
+            }
+            // dV^T += dO^T P ; dK^T += Q^T dS   (A operands: transposed reads of the dO / Q slice images)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int db = 0; db < DVB; ++db) {
+                        const int row = 32 * sub + 16 * s + tr_row;
+                        const int o1 = row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row)) << 4) + tr_byte;
+                        const int o2 = (row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row + 8)) << 4) + tr_byte;
+                        {
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dol + o1));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dol + o2));
+                            s16x8 vv;
+                            vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+                            vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+                            dVt[db] = M::run(__builtin_bit_cast(frag, vv), pP[sub][s], dVt[db]);
+                        }
+                        {
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ql + o1));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ql + o2));
+                            s16x8 vv;
+                            vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+                            vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+                            dKt[db] = M::run(__builtin_bit_cast(frag, vv), pS[sub][s], dKt[db]);
+                        }
+                    }
+        }
+        if (it + 1 < n_it) write_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: dK = scale * dK^T^T, dV = dV^T^T ; lane = key, registers = d
+    char* dkb = a.dk.ptr + ((int64_t)b * a.dk.sb + (int64_t)hk * a.dk.sh) * 2;
+    char* dvb = a.dv.ptr + ((int64_t)b * a.dv.sb + (int64_t)hk * a.dv.sh) * 2;
+    const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, a.dk_range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, a.dv_range, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) E e4;
+#pragma unroll
+    for (int db = 0; db < DVB; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 32 * db + 8 * g4 + 4 * h;
+            if (d < D) {
+                e4 pk, pv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pk[e] = (E)(dKt[db][4 * g4 + e] * a.scale);
+                    pv[e] = (E)(dVt[db][4 * g4 + e]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rdk,
+                                                      (unsigned)key * (unsigned)(a.dk.sn * 2) + (unsigned)(d * 2), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), rdv,
+                                                      (unsigned)key * (unsigned)(a.dv.sn * 2) + (unsigned)(d * 2), 0, 0);
+            }
+        }
+}
+
+// ========================================================================= dQ
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    using E = typename M::elem;
+    constexpr int DK = D / 16;
+    constexpr int DVB = (D + 31) / 32;
+    constexpr int CPR = D / 8;
+    constexpr int ROWB = (D <= 64) ? 128 : 256;
+    constexpr int TILE_BYTES = 64 * ROWB;
+    constexpr int NT = NW * 64;
+    constexpr int NCH = 64 * CPR;
+    constexpr int NLD = (NCH + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = bid % a.n_qtiles;
+    int rest = bid / a.n_qtiles;
+    const int hg = rest % a.hgroups;
+    rest /= a.hgroups;
+    const int hk = rest % a.Hkv;
+    const int b = rest / a.Hkv;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int g = a.Hq / a.Hkv;
+    const int hh = wave % a.hpw, rbi = wave / a.hpw;
+    const int head = hk * g + hg * a.hpw + hh;
+    const int N = a.N, W = a.window, ns = a.num_sink;
+    const int BM = 32 * a.rb;
+    const int q0 = qt * BM;
+    const int q1 = (q0 + BM < N) ? q0 + BM : N;
+    const int qw0 = q0 + 32 * rbi;
+    const int qw_hi = (qw0 + 31 < N - 1) ? qw0 + 31 : N - 1;
+    const int qrow = qw0 + r;
+    const bool wave_live = qw0 < N;
+
+    const int ns_eff = ns < q1 ? ns : q1;
+    const int ts_hi = (ns_eff + 63) >> 6;
+    int wlo = q0 - W + 1;
+    if (wlo < 0) wlo = 0;
+    int tw_lo = wlo >> 6;
+    if (tw_lo < ts_hi) tw_lo = ts_hi;
+    const int tw_hi = (q1 + 63) >> 6;
+    if (tw_lo > tw_hi) tw_lo = tw_hi;
+    const int nt = ts_hi + (tw_hi - tw_lo);
+
+    const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
+    const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
+    const char* kb = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
+    const char* vb = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
+    char* dqb = a.dq.ptr + ((int64_t)b * a.dq.sb + (int64_t)head * a.dq.sh) * 2;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, a.k_range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, a.v_range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void*)dqb, 0, a.dq_range, 0x00020000);
+
+    frag qf[DK], dof[DK];
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+        const unsigned qo = (unsigned)qrow * (unsigned)(a.q.sn * 2) + (unsigned)((2 * ks + h) * 16);
+        const unsigned oo = (unsigned)qrow * (unsigned)(a.d_o.sn * 2) + (unsigned)((2 * ks + h) * 16);
+        qf[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rq, qo, 0, 0));
+        dof[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rdo, oo, 0, 0));
+    }
+    float lse2 = INFINITY, dlt = 0.f;   // rows >= N: p = exp2(-inf) = 0
+    if (qrow < N) {
+        const int64_t idx = ((int64_t)b * a.Hq + head) * N + qrow;
+        lse2 = a.lse[idx] * kLog2e;
+        dlt = a.delta[idx];
+    }
+
+    u32x4 kst[NLD], vst[NLD];
+    const unsigned ksn2 = (unsigned)(a.k.sn * 2), vsn2 = (unsigned)(a.v.sn * 2);
+    auto issue_loads = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * NT;
+            const int key = c / CPR, ch = c % CPR;
+            const bool in = (NCH % NT == 0) || (c < NCH);
+            const unsigned row = (unsigned)(64 * t + key);
+            const unsigned ko = in ? row * ksn2 + (unsigned)(ch * 16) : 0xFFFFFFF0u;
+            const unsigned vo = in ? row * vsn2 + (unsigned)(ch * 16) : 0xFFFFFFF0u;
+            kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, ko, 0, 0);
+            vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
+        }
+    };
+    auto write_lds = [&](int buf) {
+        char* kl = smem + buf * 2 * TILE_BYTES;
+        char* vl = kl + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * NT;
+            const int key = c / CPR, ch = c % CPR;
+            if ((NCH % NT == 0) || (c < NCH)) {
+                const int o = key * ROWB + ((ch ^ sw<ROWB>(key)) << 4);
+                *reinterpret_cast<u32x4*>(kl + o) = kst[i];
+                *reinterpret_cast<u32x4*>(vl + o) = vst[i];
+            }
+        }
+    };
+    auto tile_of = [&](int it) { return it < ts_hi ? it : tw_lo + (it - ts_hi); };
+
+    const int rowrd = r * ROWB;
+    const int rsw = sw<ROWB>(r);               // sw(32*kh + r) == sw(r)
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int tr_row = 4 * h + q4;
+    const int tr_col = 2 * g1 + (p4 >> 1);
+    const int tr_byte = (p4 & 1) * 8;
+    const float c = a.scale_log2;
+
+    f32x16 dQt[DVB];
+#pragma unroll
+    for (int db = 0; db < DVB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQt[db][i] = 0.f;
+
+    if (nt > 0) {
+        issue_loads(tile_of(0));
+        write_lds(0);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nt) issue_loads(tile_of(it + 1));
+        const int k0 = tile_of(it) * 64;
+        const bool needed = wave_live && (k0 <= qw_hi) && (k0 < ns || k0 + 63 >= qw0 - W + 1);
+        if (needed) {
+            const bool full = (k0 + 63 <= qw0) && ((k0 + 63 < ns) || (k0 >= qw_hi - W + 1));
+            const char* kl = smem + buf * 2 * TILE_BYTES;
+            const char* vl = kl + TILE_BYTES;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                f32x16 S, dP;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    S[i] = 0.f;
+                    dP[i] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) {
+                    const int o = kh * 32 * ROWB + rowrd + (((2 * ks + h) ^ rsw) << 4);
+                    const frag kf = *reinterpret_cast<const frag*>(kl + o);
+                    const frag vf = *reinterpret_cast<const frag*>(vl + o);
+                    S = M::run(kf, qf[ks], S);
+                    dP = M::run(vf, dof[ks], dP);
+                }
+                frag pS[2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
+                    if (!full) {
+                        const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const bool valid = (key <= qrow) && (key < ns || key + W > qrow);
+                        p = valid ? p : 0.f;
+                    }
+                    pS[i >> 3][i & 7] = (E)(p * (dP[i] - dlt));
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int db = 0; db < DVB; ++db) {
+                        const int row = 32 * kh + 16 * s + tr_row;
+                        const int o1 = row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row)) << 4) + tr_byte;
+                        const int o2 = (row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row + 8)) << 4) + tr_byte;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(kl + o1));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(kl + o2));
+                        s16x8 vv;
+                        vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+                        vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+                        dQt[db] = M::run(__builtin_bit_cast(frag, vv), pS[s], dQt[db]);
+                    }
+            }
+        }
+        if (it + 1 < nt) write_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // dQ = scale * dQ^T^T (sink_flash_attention.py:481)
+    const unsigned orow = (unsigned)qrow * (unsigned)(a.dq.sn * 2);
+    typedef __attribute__((ext_vector_type(4))) E e4;
+#pragma unroll
+    for (int db = 0; db < DVB; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 32 * db + 8 * g4 + 4 * h;
+            if (d < D) {
+                e4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (E)(dQt[db][4 * g4 + e] * a.scale);
+                const unsigned off = wave_live ? orow + (unsigned)(d * 2) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rdq, off, 0, 0);
+            }
+        }
+}
+
+// ==================================================================== launch
+template <typename T, int D>
+int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
+    constexpr int ROWB = (D <= 64) ? 128 : 256;
+    {
+        constexpr int lds = 2 * (2 * 64 * ROWB + 512);
+        auto kern = bwd_dkdv_mfma_kernel<T, D>;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        const int nblk = a.n_kblocks * a.Hkv * B;
+        kern<<<dim3(nblk), dim3(256), lds, stream>>>(a);
+        int st = launch_status("bwd_dkdv_mfma");
+        if (st) return st;
+    }
+    record_stage(2, stream);
+    {
+        constexpr int NW = 8;
+        constexpr int lds = 2 * 2 * 64 * ROWB;
+        auto kern = bwd_dq_mfma_kernel<T, D, NW>;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        const int nblk = a.n_qtiles * a.hgroups * a.Hkv * B;
+        kern<<<dim3(nblk), dim3(NW * 64), lds, stream>>>(a);
+    }
+    set_path("bwd_mfma_%s_d%d_dkdv4x32_dq8w_hpw%d", DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, a.hpw);
+    return launch_status("bwd_dq_mfma");
+}
+
+template <typename T>
+int launch_bwd_d(const BwdArgs& a, int D, int B, hipStream_t stream) {
+    switch (D) {
+        case 64: return launch_bwd<T, 64>(a, B, stream);
+        case 80: return launch_bwd<T, 80>(a, B, stream);
+        case 96: return launch_bwd<T, 96>(a, B, stream);
+        case 128: return launch_bwd<T, 128>(a, B, stream);
+    }
+    set_error("bwd_mfma: unsupported head dim %d", D);
     return SFA_ERR_UNSUPPORTED;
 }
+
+int gcd(int x, int y) { return y == 0 ? x : gcd(y, x % y); }
+
+unsigned slice_range(const sfa_tensor* t) { return (unsigned)(((t->shape[2] - 1) * t->stride[2] + t->shape[3]) * 2); }
+bool slice_ok(const sfa_tensor* t) {
+    const int64_t reach = (t->shape[2] + 320) * t->stride[2] * 2 + 512;
+    return reach < (1ll << 32) - 65536 && ((uintptr_t)t->ptr % 16) == 0 && (t->stride[0] * 2) % 16 == 0 &&
+           (t->stride[1] * 2) % 16 == 0 && (t->stride[2] * 2) % 16 == 0;
+}
+
+}  // namespace
+
+bool bwd_mfma_supported(int dtype, int D) {
+    return (dtype == SFA_DTYPE_BF16 || dtype == SFA_DTYPE_F16) && (D == 64 || D == 80 || D == 96 || D == 128);
+}
+
+size_t bwd_mfma_workspace_bytes(const Problem&, int) { return 0; }
+
+int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o, const float* lse,
+             const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void*,
+             const Problem& p, hipStream_t stream) {
+    if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(d_o) && slice_ok(dq) && slice_ok(dk) && slice_ok(dv)))
+        return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, stream);
+    const int g = p.Hq / p.Hkv;
+    BwdArgs a;
+    a.q = make_view(q); a.k = make_view(k); a.v = make_view(v); a.d_o = make_view(d_o);
+    a.dq = make_view(dq); a.dk = make_view(dk); a.dv = make_view(dv);
+    a.lse = lse; a.delta = delta;
+    a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
+    a.num_sink = p.num_sink;
+    a.window = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);
+    a.scale = p.scale;
+    a.scale_log2 = p.scale * kLog2e;
+    a.q_range = slice_range(q); a.k_range = slice_range(k); a.v_range = slice_range(v); a.do_range = slice_range(d_o);
+    a.dq_range = slice_range(dq); a.dk_range = slice_range(dk); a.dv_range = slice_range(dv);
+    a.n_kblocks = (int)cdiv64(p.N, kKB);
+    a.hpw = gcd(g, 8);
+    a.rb = 8 / a.hpw;
+    a.n_qtiles = (int)cdiv64(p.N, 32 * a.rb);
+    a.hgroups = g / a.hpw;
+    if ((int64_t)a.n_qtiles * a.hgroups * p.Hkv * p.B >= (1ll << 31)) {
+        set_error("bwd_mfma: grid too large");
+        return SFA_ERR_UNSUPPORTED;
+    }
+    if (q->dtype == SFA_DTYPE_BF16) return launch_bwd_d<bf16_t>(a, p.D, p.B, stream);
+    return launch_bwd_d<f16_t>(a, p.D, p.B, stream);
+}
+
 }  // namespace sfa
