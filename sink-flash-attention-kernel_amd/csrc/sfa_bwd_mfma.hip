@@ -84,6 +84,16 @@ __device__ __forceinline__ frag tr_pair(const char* p, int rowb8) {
     return __builtin_bit_cast(frag, vv);
 }
 
+template <typename frag>
+__device__ __forceinline__ frag tr_pair2(const char* p1, const char* p2) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p2));
+    s16x8 vv;
+    vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+    vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+    return __builtin_bit_cast(frag, vv);
+}
+
 // ===================================================================== dK / dV
 constexpr int kKB = 128;   // keys per workgroup (32 per wave)
 
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
     constexpr int ROWB = (D <= 64) ? 128 : 256;
     constexpr int QT = 64;                       // query rows per iteration (two 32-row MFMA slices)
     constexpr int TILE = QT * ROWB;              // bytes of one Q (or dO) slice image
-    constexpr int STAGE = 2 * TILE + 512;        // Q | dO | -lse/scale[64] | -delta[64]
+    constexpr int STAGE = 2 * TILE + 512;        // Q | dO | -lse*log2e[64] | -delta[64]
     constexpr int NCH = QT * CPR;                // 16-byte chunks per slice
     constexpr int NLD = (NCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
             const int row = qt * QT + (tid & 63);
             const int64_t idx = ((int64_t)b * a.Hq + head) * N + row;
             if (tid < 64)
-                cst = (row < N) ? -a.lse[idx] / a.scale : -INFINITY;   // rows >= N: p = exp2(c * -inf) = 0
+                cst = (row < N) ? -a.lse[idx] * kLog2e : -INFINITY;    // rows >= N: p = exp2(-inf) = 0
             else
                 cst = (row < N) ? -a.delta[idx] : 0.f;
         }
@@ -218,10 +228,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
         const int buf = it & 1;
         if (it + 1 < n_it) issue_loads(it + 1);
         const int q0 = (qt_lo + it % nq) * QT;
-        // wave-level classification of (32 keys) x (64 rows)
-        const bool needed = (kw0 < N) && (kw0 <= q0 + 63) && (kw0 < ns || kw0 + 31 + W > q0);
-        if (needed) {
-            const bool full = (kw0 + 31 <= q0) && (q0 + 63 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 63));
+        // wave-level classification of (32 keys) x (64 rows).  The MFMAs run unconditionally (a tile the wave
+        // does not need is simply an all-masked tile): no control flow around the accumulators.
+        const bool full = (kw0 + 31 <= q0) && (q0 + 63 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 63));
+        {
             const char* st = smem + buf * STAGE;
             const char* ql = st;
             const char* dol = st + TILE;
@@ -229,17 +239,11 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
             frag pP[2][2], pS[2][2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                // initial accumulators: S' = -LSE/scale + Q K^T, dP' = -Delta + dO V^T (row = query (i&3)+8(i>>2)+4h)
                 f32x16 S, dP;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + 32 * sub + 8 * g4 + 4 * h);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(cl + 64 + 32 * sub + 8 * g4 + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        S[4 * g4 + e] = l4[e];
-                        dP[4 * g4 + e] = d4[e];
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    S[i] = 0.f;
+                    dP[i] = 0.f;
                 }
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
@@ -249,17 +253,36 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
                     S = M::run(qa, kf[ks], S);
                     dP = M::run(da, vf[ks], dP);
                 }
-                // P = exp2(c * S'), dS = P * dP'  -> packed B operands (k index = query row, permuted)
+                // row constants (row = query (i&3)+8(i>>2)+4h): nl = -LSE*log2e, nd = -Delta
+                float nl[16], nd[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float p = __builtin_amdgcn_exp2f(c * S[i]);
-                    if (!full) {
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + 32 * sub + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(cl + 64 + 32 * sub + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        nl[4 * g4 + e] = l4[e];
+                        nd[4 * g4 + e] = d4[e];
+                    }
+                }
+                // P = exp2(c*S - LSE*log2e), dS = P * (dP - Delta) -> packed B operands (k index = query row, permuted)
+                if (full) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, nl[i]));
+                        pP[sub][i >> 3][i & 7] = (E)p;
+                        pS[sub][i >> 3][i & 7] = (E)(p * (dP[i] + nd[i]));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
                         const int qi = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
                         const bool valid = (key <= qi) && (key < ns || key + W > qi) && (qi < N);
-                        p = valid ? p : 0.f;
+                        float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, nl[i]));
+                        p = valid ? p : 0.f;                      // select, not multiply: p may be inf on masked slots
+                        pP[sub][i >> 3][i & 7] = (E)p;
+                        pS[sub][i >> 3][i & 7] = (E)(p * (dP[i] + nd[i]));
                     }
-                    pP[sub][i >> 3][i & 7] = (E)p;
-                    pS[sub][i >> 3][i & 7] = (E)(p * dP[i]);
                 }
             }
             // dV^T += dO^T P ; dK^T += Q^T dS   (A operands: transposed reads of the dO / Q slice images)
@@ -272,22 +295,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
                         const int row = 32 * sub + 16 * s + tr_row;
                         const int o1 = row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row)) << 4) + tr_byte;
                         const int o2 = (row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row + 8)) << 4) + tr_byte;
-                        {
-                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dol + o1));
-                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dol + o2));
-                            s16x8 vv;
-                            vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
-                            vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
-                            dVt[db] = M::run(__builtin_bit_cast(frag, vv), pP[sub][s], dVt[db]);
-                        }
-                        {
-                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ql + o1));
-                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ql + o2));
-                            s16x8 vv;
-                            vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
-                            vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
-                            dKt[db] = M::run(__builtin_bit_cast(frag, vv), pS[sub][s], dKt[db]);
-                        }
+                        dVt[db] = M::run(tr_pair2<frag>(dol + o1, dol + o2), pP[sub][s], dVt[db]);
+                        dKt[db] = M::run(tr_pair2<frag>(ql + o1, ql + o2), pS[sub][s], dKt[db]);
                     }
         }
         if (it + 1 < n_it) write_lds(buf ^ 1);
@@ -472,15 +481,20 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
                     dP = M::run(vf, dof[ks], dP);
                 }
                 frag pS[2];
+                if (full) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
-                    if (!full) {
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
+                        pS[i >> 3][i & 7] = (E)(p * (dP[i] - dlt));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
                         const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
                         const bool valid = (key <= qrow) && (key < ns || key + W > qrow);
-                        p = valid ? p : 0.f;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
+                        pS[i >> 3][i & 7] = (E)(valid ? p * (dP[i] - dlt) : 0.f);
                     }
-                    pS[i >> 3][i & 7] = (E)(p * (dP[i] - dlt));
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
