@@ -274,10 +274,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
                         pS[sub][i >> 3][i & 7] = (E)(p * (dP[i] + nd[i]));
                     }
                 } else {
+                    int keym = key;
+                    asm volatile("; edge tile" : "+v"(keym) : : "memory");   // side effect: the branch cannot be speculated / if-converted
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int qi = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool valid = (key <= qi) && (key < ns || key + W > qi) && (qi < N);
+                        const bool valid = (keym <= qi) && (keym < ns || keym + W > qi) && (qi < N);
                         float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, nl[i]));
                         p = valid ? p : 0.f;                      // select, not multiply: p may be inf on masked slots
                         pP[sub][i >> 3][i & 7] = (E)p;
@@ -488,10 +490,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
                         pS[i >> 3][i & 7] = (E)(p * (dP[i] - dlt));
                     }
                 } else {
+                    int qm = qrow;
+                    asm volatile("; edge tile" : "+v"(qm) : : "memory");     // side effect: the branch cannot be speculated / if-converted
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool valid = (key <= qrow) && (key < ns || key + W > qrow);
+                        const bool valid = (key <= qm) && (key < ns || key + W > qm);
                         const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
                         pS[i >> 3][i & 7] = (E)(valid ? p * (dP[i] - dlt) : 0.f);
                     }

@@ -222,12 +222,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
                 }
             }
             if (!full) {
+                int qm = qrow;
+                asm volatile("; edge tile" : "+v"(qm) : : "memory");   // side effect: the branch cannot be speculated / if-converted
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool valid = (key <= qrow) && (key < ns || key + W > qrow);
+                        const bool valid = (key <= qm) && (key < ns || key + W > qm);
                         s[kh][i] = valid ? s[kh][i] : -INFINITY;
                     }
             }
