@@ -100,13 +100,59 @@ def pmc_traffic(kernel_key):
     return best
 
 
+def reduce_max_seconds(dt, device, world):
+    """Step time of the job = the slowest rank's (the contract: MAX over ranks)."""
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt
+
+
+def job_value(flops_per_rank, world, seconds_per_step):
+    """Whole-job throughput: every rank processed its own batch (weak scaling), TFLOP/s."""
+    return flops_per_rank * world / seconds_per_step / 1e12
+
+
+def dry_run(args):
+    """No GPU: each rank 'works' for (rank+1) x 10 ms per step, then the same barrier / max-over-ranks / JSON
+    logic as the real run.  Used by tests/test_multirank_gloo.py with world_size 2 on CPU."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    from oracle.sink_oracle import flops_fwd_bwd
+    w = WORKLOAD
+    f_fb = flops_fwd_bwd(w["B"], w["Hq"], w["N"], w["D"], w["ns"], w["W"])
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = reduce_max_seconds(time.perf_counter() - t0, torch.device("cpu"), world)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no kernels)", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "scaling": "weak",
+                          "value": round(job_value(f_fb, world, dt / args.steps), 3), "unit": "TFLOP/s",
+                          "global_batch": w["B"] * world}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank control path (gloo, no kernels, value is meaningless)")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,16 +210,12 @@ def main():
             torch.cuda.synchronize()
             lib.sfa_debug_set_stage_events(None, 0)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = reduce_max_seconds(time.perf_counter() - t0, dev, world)
 
     ms_per_step = dt / args.steps * 1e3
     f_fb = flops_fwd_bwd(B, Hq, N, D, ns, W)
     f_f = flops_fwd(B, Hq, N, D, ns, W)
-    value = f_fb * world / (dt / args.steps) / 1e12
+    value = job_value(f_fb, world, dt / args.steps)
 
     if rank == 0:
         fwd_ms = sorted(s.elapsed_time(e) for s, e in fwd_ev)
