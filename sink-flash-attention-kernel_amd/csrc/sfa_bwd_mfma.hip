@@ -73,6 +73,7 @@ struct BwdArgs {
     View q, k, v, d_o, dq, dk, dv;
     const float* lse;
     const float* delta;
+    const float* consts;   // [B, Hq, 2, N] f32: -LSE*log2e | -Delta (row constants of the wave-specialised dK/dV kernel)
     int B, Hq, Hkv, N;
     int num_sink, window;  // window clamped to [0, N]
     float scale, scale_log2;
@@ -115,6 +116,22 @@ __device__ __forceinline__ frag tr_pair2(const char* p1, const char* p2) {
     vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
     vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
     return __builtin_bit_cast(frag, vv);
+}
+
+// Transposed LDS read as inline asm with an immediate offset.  hipcc puts s_waitcnt vmcnt(0) in front of the
+// ds_read_tr BUILTIN whenever an LDS-DMA is in flight (may-alias), which would drain the slice prefetch every trip;
+// an asm read is invisible to that pass.  The caller waits lgkmcnt(0) + sched_barrier(0) before the first use.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read_asm(unsigned addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+__device__ __forceinline__ s16x8 join8(s16x4 lo, s16x4 hi) {
+    s16x8 vv;
+    vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+    vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+    return vv;
 }
 
 // ===================================================================== dK / dV
@@ -892,10 +909,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel_p(BwdArgs a) {
 //                are pinned in AGPRs; no big accumulators.
 //   accumulate wave (waves 4-7, same SIMD as wave-4): owns dK^T/dV^T of the group in 128 accumulators; per slice
 //                reads the 4 fragments + transposed Q/dO reads, 16 MFMAs.
-// The accumulate wave works one slice behind the score wave: one s_barrier per 32-row trip, three slice stages
-// (row reads of slice t, transposed reads of slice t-1, LDS-DMA of slice t+1) and a double-buffered exchange.
+// The accumulate wave works one slice behind the score wave: one s_barrier per 32-row trip, FOUR slice stages
+// (row reads of slice t, transposed reads of slice t-1, slice t+1 landed or landing, LDS-DMA of slice t+2 being
+// issued) and a double-buffered exchange.  A trip is ~1 us, about one memory latency, so the DMA runs three slices
+// ahead and the trip ends on a COUNTED s_waitcnt vmcnt(2) + raw s_barrier (never vmcnt(0) in the loop).  Both roles
+// issue the big LDS read burst of their NEXT trip (row fragments of slice t+1 / transposed fragments of slice t) at
+// the end of the current one, so MFMAs start right after the barrier and the burst overlaps the other role's work.
 // Loop hygiene (measured with s_memtime stamps, tools/stamps.py): no integer division in the loop (slice
-// coordinates advance incrementally), descriptors rebuilt only when the q head changes, trips unrolled x3 so
+// coordinates advance incrementally), descriptors rebuilt only when the q head changes, trips unrolled x4 so
 // the stage offset of every ds_read is an immediate, per-lane swizzled offsets hoisted.
 template <typename T, int D>
 __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
@@ -913,7 +934,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     constexpr int NSLOT = QT * CPRD;                  // 16-byte slots per slice image (512 or 256)
     constexpr int XBYTES = 4 * 1024;                  // exchange per key group: pP[0], pP[1], pS[0], pS[1]
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xch = smem + 3 * STAGE;                     // [2 buffers][4 key groups][XBYTES]
+    constexpr int NST = 4;
+    char* xch = smem + NST * STAGE;                   // [2 buffers][4 key groups][XBYTES]
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int kb = bid % a.n_kblocks;
@@ -954,20 +976,25 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const unsigned vod0 = (unsigned)drow * (unsigned)(a.d_o.sn * 2) + (unsigned)(dch * 16);
     const unsigned qstep = (unsigned)(QT * a.q.sn * 2), dstep = (unsigned)(QT * a.d_o.sn * 2);
     int ld_hh = 0, ld_qt = qt_lo;
-    __amdgpu_buffer_rsrc_t rq, rdo;
-    const float* cptr = nullptr;                                  // lse (tid<32) or delta (32<=tid<64) row pointer
+    __amdgpu_buffer_rsrc_t rq, rdo, rc;
+    const unsigned voc0 = (unsigned)((lane < 32 ? 0 : N) + (lane & 31)) * 4u;   // wave 0: -LSE*log2e | -Delta rows
     auto set_head = [&](int hh) {
         const int head = hk * g + hh;
         const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
         const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
         rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
         rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
-        cptr = ((tid < 32) ? a.lse : a.delta) + ((int64_t)b * a.Hq + head) * N;
+        rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.consts + ((int64_t)b * a.Hq + head) * 2 * N), 0,
+                                               (unsigned)(2 * N * 4), 0x00020000);
     };
-    float cst = 0.f;
-    bool cst_oob = false;
     auto stage_next = [&](int stage_off) {     // stage_off = byte offset of the destination stage (compile-time at call sites)
         if (ld_qt == qt_lo) set_head(ld_hh);
+        // the loop issues nothing but LDS-DMA: an ordinary global load next to in-flight DMAs makes hipcc drain
+        // vmcnt(0) first.  Wave 0 also brings the slice's 64 row constants (rows >= N of the Delta half read 0; of
+        // the LSE half they read finite garbage that only edge tiles can see, and those mask by row < N).
+        if (wave == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (__attribute__((address_space(3))) void*)(smem + stage_off + 2 * TILE),
+                                                     4, voc0 + (unsigned)ld_qt * (unsigned)(QT * 4), 0, 0, 0);
         if (dma_lane) {
             const unsigned qo = din ? voq0 + (unsigned)ld_qt * qstep : 0xFFFFFFF0u;
             const unsigned oo = din ? vod0 + (unsigned)ld_qt * dstep : 0xFFFFFFF0u;
@@ -975,28 +1002,31 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)dstq, 16, qo, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dstq + TILE), 16, oo, 0, 0, 0);
         }
-        if (tid < 64) {    // raw value only: converting here would wait a full memory latency inside the loop
-            const int row = ld_qt * QT + (tid & 31);
-            cst = cptr[row < N ? row : N - 1];
-            cst_oob = row >= N;
-        }
         if (++ld_qt == qt_hi) {
             ld_qt = qt_lo;
             ++ld_hh;
         }
     };
-    auto write_consts = [&](int stage_off) {
-        if (tid < 64)
-            *reinterpret_cast<float*>(smem + stage_off + 2 * TILE + tid * 4) =
-                (tid < 32) ? (cst_oob ? -INFINITY : -cst * kLog2e) : (cst_oob ? 0.f : -cst);
-    };
 
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
     const float c = a.scale_log2;
 
+    // end of a trip: slice t+1 must have landed (its DMAs are older than the ones just issued: 3 on wave 0, 2 on
+    // the others), exchange writes done
+    auto trip_sync = [&](bool more) {
+        if (!more)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (wave == 0)
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);   // nothing (MFMAs on prefetched fragments included) moves above the barrier
+    };
     if (n_it > 0) {
         stage_next(0);
-        write_consts(0);
+        if (n_it > 1) stage_next(STAGE);
+        if (n_it > 2) stage_next(2 * STAGE);
     }
     __syncthreads();
     const int n_trips = n_it + 1;
@@ -1033,39 +1063,50 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
         int q0 = qt_lo * QT;          // first row of the slice being scored
         int sc_q = 0;                 // slices scored for the current head
 
-        auto score = [&](auto full_tag, auto stage_tag, int par) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            constexpr int SOFF = decltype(stage_tag)::value * STAGE;
-            const char* ql = smem + SOFF;
-            const char* dol = smem + SOFF + TILE;
-            const float* cl = reinterpret_cast<const float*>(smem + SOFF + 2 * TILE);
-            frag qa[DK], da[DK];
+        STAMP_DECL
+        // operand fragments + row constants of the slice to score next (filled one trip ahead)
+        frag qa[DK], da[DK];
+        f32x4 l4[4], d4[4];
+        auto prefetch_q = [&](auto stage_tag) {
+            const char* ql = smem + decltype(stage_tag)::value * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                qa[ks] = *reinterpret_cast<const frag*>(ql + rdo_[ks]);
-                da[ks] = *reinterpret_cast<const frag*>(dol + rdo_[ks]);
-            }
-            f32x4 l4[4], d4[4];
+            for (int ks = 0; ks < DK; ++ks) qa[ks] = *reinterpret_cast<const frag*>(ql + rdo_[ks]);
+        };
+        auto prefetch_d = [&](auto stage_tag) {
+            const char* dol = smem + decltype(stage_tag)::value * STAGE + TILE;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) da[ks] = *reinterpret_cast<const frag*>(dol + rdo_[ks]);
+        };
+        auto prefetch_c = [&](auto stage_tag) {
+            const float* cl = reinterpret_cast<const float*>(smem + decltype(stage_tag)::value * STAGE + 2 * TILE);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 l4[g4] = *reinterpret_cast<const f32x4*>(cl + 8 * g4 + 4 * h);
                 d4[g4] = *reinterpret_cast<const f32x4*>(cl + 32 + 8 * g4 + 4 * h);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        // Q fragments of slice t+1 (stage next_tag, resident since the end of trip t-1; past the last slice the stage
+        // is allocated but stale and the fragments unused) are fetched right after the S chain has consumed the
+        // current ones, so the S chain of the next trip starts straight after the barrier; the dO fragments and row
+        // constants of the current slice are fetched at trip start, under the S chain (no registers to hold more)
+        auto score = [&](auto full_tag, auto cur_tag, auto next_tag, int par) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            prefetch_d(cur_tag);
+            prefetch_c(cur_tag);
+            STAMP(1)
             f32x16 S, dP;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 S[i] = 0.f;
                 dP[i] = 0.f;
             }
+            // S chain first; its exp2 work is then issued in the shadow of the dP chain (independent of it)
 #pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                S = M::run(qa[ks], kf[ks], S);
-                dP = M::run(da[ks], vf[ks], dP);
-            }
-            frag pP[2], pS[2];
+            for (int ks = 0; ks < DK; ++ks) S = M::run(qa[ks], kf[ks], S);
+            prefetch_q(next_tag);
+            float pf[16];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
+            for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g4 + e;
@@ -1075,44 +1116,71 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
                         const bool valid = (key <= qi) && (key < ns || key + W > qi) && (qi < N);
                         p = valid ? p : 0.f;
                     }
-                    pP[i >> 3][i & 7] = (E)p;
-                    pS[i >> 3][i & 7] = (E)(p * (dP[i] + d4[g4][e]));
+                    pf[i] = p;
+                }
+            STAMP(2)
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) dP = M::run(da[ks], vf[ks], dP);
+            if constexpr (FULL) {
+                // 1 MFMA then a few VALU/transcendental ops, repeated: the p = exp2(..) work fills the dP chain
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
                 }
             }
+            frag pP[2], pS[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                pP[i >> 3][i & 7] = (E)pf[i];
+                pS[i >> 3][i & 7] = (E)(pf[i] * (dP[i] + d4[i >> 2][i & 3]));
+            }
+            STAMP(3)
             char* x = const_cast<char*>(xw) + par * (4 * XBYTES);
             *reinterpret_cast<frag*>(x) = pP[0];
             *reinterpret_cast<frag*>(x + 1024) = pP[1];
             *reinterpret_cast<frag*>(x + 2048) = pS[0];
             *reinterpret_cast<frag*>(x + 3072) = pS[1];
         };
-        // trip t (t % 3 == K): score slice t from stage K, DMA slice t+1 into stage (K+1)%3
+        // trip t (t % 4 == K): DMA slice t+2 into stage (K+2)%4, score slice t from stage K
         auto trip = [&](auto ktag, int t) {
             constexpr int K = decltype(ktag)::value;
-            constexpr int KN = (K + 1) % 3;
-            if (t + 1 < n_it) stage_next(KN * STAGE);
+            STAMP(7)
+            if (t + 3 < n_it) stage_next(((K + 3) % NST) * STAGE);
+            STAMP(0)
             if (t < n_it) {
                 const bool full = (kw0 + 31 <= q0) && (q0 + 31 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 31));
                 if (full)
-                    score(std::true_type{}, ktag, t & 1);
+                    score(std::true_type{}, ktag, std::integral_constant<int, (K + 1) % NST>{}, t & 1);
                 else
-                    score(std::false_type{}, ktag, t & 1);
+                    score(std::false_type{}, ktag, std::integral_constant<int, (K + 1) % NST>{}, t & 1);
                 q0 += QT;
                 if (++sc_q == nq) {
                     sc_q = 0;
                     q0 = qt_lo * QT;
                 }
             }
-            if (t + 1 < n_it) write_consts(KN * STAGE);
-            __syncthreads();
+            STAMP(4)
+            trip_sync(t + 3 < n_it);
+            STAMP(5)
         };
+        if (n_it > 0) prefetch_q(std::integral_constant<int, 0>{});
         int t = 0;
-        for (; t + 3 <= n_trips; t += 3) {
+        for (; t + 4 <= n_trips; t += 4) {
             trip(std::integral_constant<int, 0>{}, t);
             trip(std::integral_constant<int, 1>{}, t + 1);
             trip(std::integral_constant<int, 2>{}, t + 2);
+            trip(std::integral_constant<int, 3>{}, t + 3);
         }
         if (t < n_trips) trip(std::integral_constant<int, 0>{}, t++);
         if (t < n_trips) trip(std::integral_constant<int, 1>{}, t++);
+        if (t < n_trips) trip(std::integral_constant<int, 2>{}, t++);
+#ifdef SFA_STAMPS
+        if (kb == 40 && hk == 0 && b == 0 && lane == 0) {
+            for (int kk = 0; kk < 8; ++kk) g_stamps[wave * 8 + kk] = ts_acc_[kk];
+            g_stamps[wave * 8 + 6] = (unsigned long long)n_it;
+        }
+#endif
     } else {
         // ------------------------------------------------------------------ accumulate waves
         f32x16 dKt[DVB], dVt[DVB];
@@ -1127,57 +1195,83 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
         const int tr_row = 4 * h + q4;
         const int tr_col = 2 * g1 + (p4 >> 1);
         const int tr_byte = (p4 & 1) * 8;
-        int to1[DVB], to2[DVB];
+        const unsigned smem_base = (unsigned)(size_t)smem;   // LDS byte address of the dynamic region
+        unsigned ta1[DVB], ta2[DVB];
 #pragma unroll
         for (int db = 0; db < DVB; ++db) {
-            to1[db] = tr_row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row)) << 4) + tr_byte;
-            to2[db] = (tr_row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row + 8)) << 4) + tr_byte;
+            ta1[db] = smem_base + (unsigned)(tr_row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row)) << 4) + tr_byte);
+            ta2[db] = smem_base + (unsigned)((tr_row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row + 8)) << 4) + tr_byte);
         }
         const char* xr = xch + kg * XBYTES + lane * 16;
-        // trip t (t % 3 == K): accumulate slice t-1 from stage (K+2)%3, DMA slice t+1 into stage (K+1)%3
+        // transposed fragments of the slice to accumulate next (asm reads issued one trip ahead, see tr_read_asm;
+        // they are waited for by the lgkmcnt(0) of trip_sync)
+        s16x4 dlo[2][DVB], dhi[2][DVB], qlo[2][DVB], qhi[2][DVB];
+        auto prefetch = [&](auto stage_tag) {
+            constexpr int QOFF = decltype(stage_tag)::value * STAGE, DOFF = QOFF + TILE;
+            auto ld = [&](auto stag, auto dbtag) {
+                constexpr int S_ = decltype(stag)::value, DB_ = decltype(dbtag)::value;
+                if constexpr (DB_ < DVB) {
+                    dlo[S_][DB_] = tr_read_asm<DOFF + 16 * S_ * ROWB>(ta1[DB_]);
+                    dhi[S_][DB_] = tr_read_asm<DOFF + 16 * S_ * ROWB>(ta2[DB_]);
+                    qlo[S_][DB_] = tr_read_asm<QOFF + 16 * S_ * ROWB>(ta1[DB_]);
+                    qhi[S_][DB_] = tr_read_asm<QOFF + 16 * S_ * ROWB>(ta2[DB_]);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            ld(I0{}, I0{}); ld(I0{}, I1{}); ld(I0{}, I2{}); ld(I0{}, I3{});
+            ld(I1{}, I0{}); ld(I1{}, I1{}); ld(I1{}, I2{}); ld(I1{}, I3{});
+        };
+        // trip t (t % 4 == K): DMA slice t+3 into stage (K+3)%4, accumulate slice t-1 (fragments fetched last trip),
+        // then fetch slice t's transposed fragments from stage K for the next trip
+        STAMP_DECL
         auto trip = [&](auto ktag, int t) {
             constexpr int K = decltype(ktag)::value;
-            constexpr int KN = (K + 1) % 3;
-            constexpr int KP = (K + 2) % 3;
-            if (t + 1 < n_it) stage_next(KN * STAGE);
+            STAMP(7)
+            if (t + 3 < n_it) stage_next(((K + 3) % NST) * STAGE);
+            STAMP(0)
             if (t >= 1) {
-                const char* ql = smem + KP * STAGE;
-                const char* dol = smem + KP * STAGE + TILE;
                 const char* x = xr + ((t - 1) & 1) * (4 * XBYTES);
                 frag pP[2], pS[2];
                 pP[0] = *reinterpret_cast<const frag*>(x);
                 pP[1] = *reinterpret_cast<const frag*>(x + 1024);
                 pS[0] = *reinterpret_cast<const frag*>(x + 2048);
                 pS[1] = *reinterpret_cast<const frag*>(x + 3072);
-                frag at[2][DVB], qtf[2][DVB];
+                STAMP(1)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int db = 0; db < DVB; ++db) {
-                        // sw(row + 16) == sw(row): the 16*s row step is a plain byte offset
-                        at[s][db] = tr_pair2<frag>(dol + 16 * s * ROWB + to1[db], dol + 16 * s * ROWB + to2[db]);
-                        qtf[s][db] = tr_pair2<frag>(ql + 16 * s * ROWB + to1[db], ql + 16 * s * ROWB + to2[db]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int db = 0; db < DVB; ++db) {
-                        dVt[db] = M::run(at[s][db], pP[s], dVt[db]);
-                        dKt[db] = M::run(qtf[s][db], pS[s], dKt[db]);
+                        dVt[db] = M::run(__builtin_bit_cast(frag, join8(dlo[s][db], dhi[s][db])), pP[s], dVt[db]);
+                        dKt[db] = M::run(__builtin_bit_cast(frag, join8(qlo[s][db], qhi[s][db])), pS[s], dKt[db]);
                     }
             }
-            if (t + 1 < n_it) write_consts(KN * STAGE);
-            __syncthreads();
+            STAMP(3)
+            if (t < n_it) {
+                __builtin_amdgcn_sched_barrier(0);   // the asm reads overwrite the fragments: MFMAs above must be issued first
+                prefetch(ktag);
+            }
+            trip_sync(t + 3 < n_it);
+            STAMP(5)
         };
         int t = 0;
-        for (; t + 3 <= n_trips; t += 3) {
+        for (; t + 4 <= n_trips; t += 4) {
             trip(std::integral_constant<int, 0>{}, t);
             trip(std::integral_constant<int, 1>{}, t + 1);
             trip(std::integral_constant<int, 2>{}, t + 2);
+            trip(std::integral_constant<int, 3>{}, t + 3);
         }
         if (t < n_trips) trip(std::integral_constant<int, 0>{}, t++);
         if (t < n_trips) trip(std::integral_constant<int, 1>{}, t++);
+        if (t < n_trips) trip(std::integral_constant<int, 2>{}, t++);
+#ifdef SFA_STAMPS
+        if (kb == 40 && hk == 0 && b == 0 && lane == 0) {
+            for (int kk = 0; kk < 8; ++kk) g_stamps[wave * 8 + kk] = ts_acc_[kk];
+            g_stamps[wave * 8 + 6] = (unsigned long long)n_it;
+        }
+#endif
 
         char* dkb = a.dk.ptr + ((int64_t)b * a.dk.sb + (int64_t)hk * a.dk.sh) * 2;
         char* dvb = a.dv.ptr + ((int64_t)b * a.dv.sb + (int64_t)hk * a.dv.sh) * 2;
@@ -1412,6 +1506,17 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
         }
 }
 
+// row constants for the wave-specialised dK/dV kernel: consts[b,h,0,:] = -LSE*log2e, consts[b,h,1,:] = -Delta
+__global__ __launch_bounds__(256) void bwd_consts_kernel(const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        float* __restrict__ consts, int N, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t bh = i / N;
+    const int n = (int)(i - bh * N);
+    consts[(bh * 2) * N + n] = -lse[i] * kLog2e;
+    consts[(bh * 2 + 1) * N + n] = -delta[i];
+}
+
 // ==================================================================== launch
 template <typename T, int D>
 int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
@@ -1425,7 +1530,12 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
     }();
     const int use_w8 = mode == 1;
     if (mode == 3) {
-        constexpr int lds = 3 * (2 * 32 * ROWB + 256) + 2 * 4 * 4096;
+        {
+            const int64_t total = (int64_t)B * a.Hq * a.N;
+            bwd_consts_kernel<<<dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream>>>(
+                a.lse, a.delta, const_cast<float*>(a.consts), a.N, total);
+        }
+        constexpr int lds = 4 * (2 * 32 * ROWB + 256) + 2 * 4 * 4096;
         auto kern = bwd_dkdv_mfma_kernel_ws<T, D>;
         static bool done = false;
         if (!done) {
@@ -1517,10 +1627,10 @@ bool bwd_mfma_supported(int dtype, int D) {
     return (dtype == SFA_DTYPE_BF16 || dtype == SFA_DTYPE_F16) && (D == 64 || D == 80 || D == 96 || D == 128);
 }
 
-size_t bwd_mfma_workspace_bytes(const Problem&, int) { return 0; }
+size_t bwd_mfma_workspace_bytes(const Problem& p, int) { return (size_t)p.B * p.Hq * p.N * 2 * sizeof(float); }
 
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o, const float* lse,
-             const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void*,
+             const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void* workspace,
              const Problem& p, hipStream_t stream) {
     if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(d_o) && slice_ok(dq) && slice_ok(dk) && slice_ok(dv)))
         return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, stream);
@@ -1529,6 +1639,7 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.q = make_view(q); a.k = make_view(k); a.v = make_view(v); a.d_o = make_view(d_o);
     a.dq = make_view(dq); a.dk = make_view(dk); a.dv = make_view(dv);
     a.lse = lse; a.delta = delta;
+    a.consts = reinterpret_cast<const float*>(workspace);
     a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
     a.num_sink = p.num_sink;
     a.window = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);

@@ -28,7 +28,7 @@ lib = _native.lib()
 buf = (ctypes.c_ulonglong * 64)()
 lib.sfa_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 rc = lib.sfa_debug_read_stamps(buf)
-names = ["issue_loads/dma", "score(S,dP,exp,pack)", "exp/pack valu", "accumulate(dV,dK)", "write_consts", "barrier", "(n_it)", "loop-top gap"]
+names = ["dma issue", "lds reads landed", "S chain + exp (score)", "dP chain+pack (score) / MFMAs (acc)", "lds write (score)", "waitcnt+barrier", "(n_it)", "loop-top gap"]
 print("rc", rc, _native.last_path())
 for w in range(8):
     vals = [buf[w * 8 + i] for i in range(8)]
@@ -37,4 +37,4 @@ for w in range(8):
     tot = sum(vals[i] for i in (0, 1, 2, 3, 4, 5, 7))
     print(f"wave {w}: n_it={n_it} total={tot} cycles/iter={tot / max(n_it, 1):.0f}")
     for i in (7, 0, 1, 2, 3, 4, 5):
-        print(f"    {names[i]:22s} {vals[i]:12d}  {vals[i] / max(n_it, 1):8.0f}/iter  {100.0 * vals[i] / max(tot, 1):5.1f}%")
+        print(f"    {names[i]:36s} {vals[i]:12d}  {vals[i] / max(n_it, 1):8.0f}/iter  {100.0 * vals[i] / max(tot, 1):5.1f}%")
