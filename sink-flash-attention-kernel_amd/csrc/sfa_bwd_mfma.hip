@@ -967,17 +967,25 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const int nq = qt_hi - qt_lo;
     const int n_it = g * nq;
 
-    // ---- slice loader state (all 512 threads): next slice to stage = (ld_hh, ld_qt); per-lane source offsets fixed
-    const bool dma_lane = (NSLOT == 512) || wave < 4;
-    const int drow = tid / CPRD;                                  // row of this lane's 16-byte slot in the image
-    const int dch = (tid % CPRD) ^ sw<ROWB>(drow);                // source chunk (swizzle on the source side)
-    const bool din = dma_lane && dch < CPR;
-    const unsigned voq0 = (unsigned)drow * (unsigned)(a.q.sn * 2) + (unsigned)(dch * 16);
-    const unsigned vod0 = (unsigned)drow * (unsigned)(a.d_o.sn * 2) + (unsigned)(dch * 16);
+    // ---- slice loader: ONLY the accumulate waves stage slices (they idle at the barrier; on the score waves the
+    // ~350 cycles of counter / descriptor / M0 work per trip were critical-path time).  Next slice = (ld_hh, ld_qt);
+    // per-lane source offsets are fixed, the swizzle is applied to the source chunk (the DMA fills LDS linearly).
+    constexpr int NDW = NSLOT / 256;                              // DMA instructions per tensor per loader wave
+    const int lw = wave - 4;                                      // loader wave index 0..3 (accumulate role)
+    unsigned voq0[NDW], vod0[NDW];
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) {
+        const int cidx = i * 256 + lw * 64 + lane;
+        const int drow = cidx / CPRD;
+        const int dch = (cidx % CPRD) ^ sw<ROWB>(drow);
+        const bool din = dch < CPR;
+        voq0[i] = din ? (unsigned)drow * (unsigned)(a.q.sn * 2) + (unsigned)(dch * 16) : 0xFFFFFFF0u;
+        vod0[i] = din ? (unsigned)drow * (unsigned)(a.d_o.sn * 2) + (unsigned)(dch * 16) : 0xFFFFFFF0u;
+    }
     const unsigned qstep = (unsigned)(QT * a.q.sn * 2), dstep = (unsigned)(QT * a.d_o.sn * 2);
     int ld_hh = 0, ld_qt = qt_lo;
     __amdgpu_buffer_rsrc_t rq, rdo, rc;
-    const unsigned voc0 = (unsigned)((lane < 32 ? 0 : N) + (lane & 31)) * 4u;   // wave 0: -LSE*log2e | -Delta rows
+    const unsigned voc0 = (unsigned)((lane < 32 ? 0 : N) + (lane & 31)) * 4u;   // wave 4: -LSE*log2e | -Delta rows
     auto set_head = [&](int hh) {
         const int head = hk * g + hh;
         const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
@@ -988,17 +996,19 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
                                                (unsigned)(2 * N * 4), 0x00020000);
     };
     auto stage_next = [&](int stage_off) {     // stage_off = byte offset of the destination stage (compile-time at call sites)
+        if (!acc_role) return;
         if (ld_qt == qt_lo) set_head(ld_hh);
         // the loop issues nothing but LDS-DMA: an ordinary global load next to in-flight DMAs makes hipcc drain
-        // vmcnt(0) first.  Wave 0 also brings the slice's 64 row constants (rows >= N of the Delta half read 0; of
+        // vmcnt(0) first.  Wave 4 also brings the slice's 64 row constants (rows >= N of the Delta half read 0; of
         // the LSE half they read finite garbage that only edge tiles can see, and those mask by row < N).
-        if (wave == 0)
+        if (lw == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (__attribute__((address_space(3))) void*)(smem + stage_off + 2 * TILE),
                                                      4, voc0 + (unsigned)ld_qt * (unsigned)(QT * 4), 0, 0, 0);
-        if (dma_lane) {
-            const unsigned qo = din ? voq0 + (unsigned)ld_qt * qstep : 0xFFFFFFF0u;
-            const unsigned oo = din ? vod0 + (unsigned)ld_qt * dstep : 0xFFFFFFF0u;
-            char* dstq = smem + stage_off + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) {
+            const unsigned qo = voq0[i] == 0xFFFFFFF0u ? voq0[i] : voq0[i] + (unsigned)ld_qt * qstep;
+            const unsigned oo = vod0[i] == 0xFFFFFFF0u ? vod0[i] : vod0[i] + (unsigned)ld_qt * dstep;
+            char* dstq = smem + stage_off + (i * 256 + lw * 64) * 16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)dstq, 16, qo, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dstq + TILE), 16, oo, 0, 0, 0);
         }
@@ -1011,15 +1021,15 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
     const float c = a.scale_log2;
 
-    // end of a trip: slice t+1 must have landed (its DMAs are older than the ones just issued: 3 on wave 0, 2 on
-    // the others), exchange writes done
+    // end of a trip: on the loader waves everything but the DMAs just issued (2*NDW, +1 on wave 4) must have
+    // landed; exchange writes / fragment reads done
     auto trip_sync = [&](bool more) {
-        if (!more)
+        if (!acc_role || !more)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (wave == 0)
-            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (lw == 0)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDW + 1) : "memory");
         else
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDW) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);   // nothing (MFMAs on prefetched fragments included) moves above the barrier
     };
@@ -1442,6 +1452,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
                     S[i] = 0.f;
                     dP[i] = 0.f;
                 }
+                // (batching the K/V fragment reads ahead of the chains, as the forward does, costs 26 more VGPRs here
+                // and measured slower: 2.47 vs 2.33 ms at C3)
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
                     const int o = kh * 32 * ROWB + rowrd + (((2 * ks + h) ^ rsw) << 4);

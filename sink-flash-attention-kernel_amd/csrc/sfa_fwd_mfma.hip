@@ -209,18 +209,27 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
             const char* kl = smem + buf * 2 * TILE_BYTES;
             const char* vl = kl + TILE_BYTES;
             // S^T tiles: rows = 32 keys (two halves), cols = the wave's 32 query rows
+            // K fragments in bursts (one 32-key half ahead of the MFMA chain that consumes it): left alone, hipcc sinks
+            // every ds_read next to its MFMA and the wave pays the LDS latency once per k-step
             f32x16 s[2];
+            frag kfa[DK], kfb[DK];
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
+            for (int ks = 0; ks < DK; ++ks)
+                kfa[ks] = *reinterpret_cast<const frag*>(kl + k_rowoff + (((2 * ks + h) ^ ksw_l) << 4));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[kh][i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < DK; ++ks) {
-                    const frag kf = *reinterpret_cast<const frag*>(kl + kh * 32 * ROWB + k_rowoff +
-                                                                   (((2 * ks + h) ^ ksw_l) << 4));
-                    s[kh] = M::run(kf, qf[ks], s[kh]);
-                }
+            for (int i = 0; i < 16; ++i) {
+                s[0][i] = 0.f;
+                s[1][i] = 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                kfb[ks] = *reinterpret_cast<const frag*>(kl + 32 * ROWB + k_rowoff + (((2 * ks + h) ^ ksw_l) << 4));
+                s[0] = M::run(kfa[ks], qf[ks], s[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) s[1] = M::run(kfb[ks], qf[ks], s[1]);
             if (!full) {
                 int qm = qrow;
                 asm volatile("; edge tile" : "+v"(qm) : : "memory");   // side effect: the branch cannot be speculated / if-converted
