@@ -121,6 +121,20 @@ int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, co
                const float* s_aux, void* workspace, size_t workspace_bytes, float scale,
                unsigned flags, void* stream);
 
+/*
+ * Decode over a sink + sliding-window KV cache WITHOUT linearising it.  Replaces the
+ * get_kv() torch.cat copies of sink_attention/cache.py:185-216 followed by sink_decode_attention: the kernel reads
+ * rows [0, sink_len) of the sink buffer and rows [0, window_len) of the window ring in place (softmax does not care
+ * about key order, so a wrapped ring needs no reordering).
+ *   sink_k/v   [B, Hkv, num_sink, D]     sink_len   <= num_sink   valid rows
+ *   window_k/v [B, Hkv, window_size, D]  window_len <= window_size valid slots (all of them once the ring is full)
+ *   workspace: sfa_decode_workspace_bytes(B, Hq, Hkv, sink_len + window_len, D, dtype)
+ */
+int sfa_decode_ring(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v, int64_t sink_len,
+                    const sfa_tensor* window_k, const sfa_tensor* window_v, int64_t window_len,
+                    const sfa_tensor* o, const float* s_aux, void* workspace, size_t workspace_bytes,
+                    float scale, unsigned flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,10 +186,14 @@ size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nk
     return align256((size_t)B * Hq * pl.splits * (size_t)(D + 2) * sizeof(float));
 }
 
-int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
-               const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
-               void* stream) {
-    (void)flags;
+}  // extern "C"
+
+namespace {
+
+// shared by sfa_decode (one contiguous key segment) and sfa_decode_ring (sink buffer + window ring)
+int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
+                  const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
+                  size_t workspace_bytes, float scale, void* stream) {
     g_err[0] = 0;
     int st;
     if ((st = check_tensor(q, "q")) || (st = check_tensor(k, "k")) || (st = check_tensor(v, "v")) ||
@@ -203,26 +207,60 @@ int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, co
     SFA_CHECK_ARG(k->shape[1] > 0 && q->shape[1] % k->shape[1] == 0, "H_q (%lld) must be divisible by H_kv (%lld)",
                   (long long)q->shape[1], (long long)k->shape[1]);
     SFA_CHECK_ARG(std::isfinite(scale), "scale must be finite");
-    SFA_CHECK_ARG(k->shape[2] < (1ll << 31) - 4096, "N_kv too large");
+    SFA_CHECK_ARG(n1 >= 0 && n1 <= k->shape[2], "first key segment: %lld valid rows of %lld", (long long)n1,
+                  (long long)k->shape[2]);
+    if (k2 || v2 || n2) {
+        SFA_CHECK_ARG(k2 && v2, "second key segment needs both k and v");
+        if ((st = check_tensor(k2, "k2")) || (st = check_tensor(v2, "v2")) || (st = same_shape(k2, v2, "k2", "v2")))
+            return st;
+        SFA_CHECK_ARG(k2->dtype == k->dtype && k2->shape[0] == k->shape[0] && k2->shape[1] == k->shape[1] &&
+                          k2->shape[3] == k->shape[3],
+                      "the two key segments must agree in dtype, batch, heads and head dim");
+        SFA_CHECK_ARG(n2 >= 0 && n2 <= k2->shape[2], "second key segment: %lld valid rows of %lld", (long long)n2,
+                      (long long)k2->shape[2]);
+    }
+    SFA_CHECK_ARG(n1 + n2 < (1ll << 31) - 4096, "N_kv too large");
     if (q->shape[0] == 0 || q->shape[1] == 0) return SFA_OK;
     DecodePlan pl;
-    st = decode_plan(q->shape[0], q->shape[1], k->shape[1], k->shape[2], q->shape[3], q->dtype, &pl);
+    st = decode_plan(q->shape[0], q->shape[1], k->shape[1], n1 + n2, q->shape[3], q->dtype, &pl);
     if (st) return st;
     const int es = dtype_size(q->dtype);
-    const sfa_tensor* ts[3] = {q, k, v};
+    const sfa_tensor* ts[5] = {q, k, v, k2, v2};
     for (const sfa_tensor* t : ts) {
+        if (!t || t->shape[2] == 0) continue;
         SFA_CHECK_ARG(((uintptr_t)t->ptr % 16) == 0 && (t->stride[0] * es) % 16 == 0 && (t->stride[1] * es) % 16 == 0 &&
                           (t->stride[2] * es) % 16 == 0,
                       "decode: q/k/v rows must be 16-byte aligned");
     }
-    const size_t need = sfa_decode_workspace_bytes(q->shape[0], q->shape[1], k->shape[1], k->shape[2], q->shape[3],
-                                                  q->dtype);
+    const size_t need = sfa_decode_workspace_bytes(q->shape[0], q->shape[1], k->shape[1], n1 + n2, q->shape[3], q->dtype);
     if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 255) != 0) {
         set_error("decode workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", need, workspace_bytes,
                   workspace);
         return SFA_ERR_WORKSPACE;
     }
-    return decode_launch(q, k, v, o, s_aux, workspace, scale, pl, (hipStream_t)stream);
+    return decode_launch(q, k, v, n1, n2 ? k2 : nullptr, n2 ? v2 : nullptr, n2, o, s_aux, workspace, scale, pl,
+                         (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+               const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
+               void* stream) {
+    (void)flags;
+    return decode_common(q, k, v, k ? k->shape[2] : 0, nullptr, nullptr, 0, o, s_aux, workspace, workspace_bytes, scale,
+                         stream);
+}
+
+int sfa_decode_ring(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v, int64_t sink_len,
+                    const sfa_tensor* window_k, const sfa_tensor* window_v, int64_t window_len, const sfa_tensor* o,
+                    const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
+                    void* stream) {
+    (void)flags;
+    return decode_common(q, sink_k, sink_v, sink_len, window_k, window_v, window_len, o, s_aux, workspace,
+                         workspace_bytes, scale, stream);
 }
 
 }  // extern "C"

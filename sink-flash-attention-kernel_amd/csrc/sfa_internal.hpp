@@ -34,7 +34,9 @@ struct DecodePlan {
     int gt;              // q heads of a GQA group processed per pass
 };
 int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype, DecodePlan* plan);
-int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
-                  const float* s_aux, void* workspace, float scale, const DecodePlan& plan, hipStream_t stream);
+// keys = rows [0, n1) of (k, v) followed by rows [0, n2) of (k2, v2); k2/v2 may be null when n2 == 0
+int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
+                  const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
+                  float scale, const DecodePlan& plan, hipStream_t stream);
 
 }  // namespace sfa

@@ -1,9 +1,10 @@
 """sink_attention (MI355X / gfx950): drop-in for the hot path of
 RulinShao/sink-flash-attention-kernel -- same import name and public names for
 ``sink_flash_attention``, ``sink_decode_attention``, ``patch_verl_with_sink_attention``
-and ``unpatch_verl``; kernels are hand-written HIP behind libsfa.so (no Triton)."""
+and ``unpatch_verl`` (plus the sink + ring KV cache with a copy-free decode); kernels are hand-written HIP behind libsfa.so (no Triton)."""
 from .sink_flash_attention import sink_flash_attention, SinkFlashAttentionFunc
-from .decode_kernel import sink_decode_attention
+from .decode_kernel import sink_decode_attention, sink_decode_attention_ring
+from .cache import SinkCacheLayer, SinkAttentionCache
 from .verl_patch import patch_verl_with_sink_attention, unpatch_verl
 
 __version__ = "0.1.0"
@@ -14,4 +15,7 @@ __all__ = [
     "patch_verl_with_sink_attention",
     "unpatch_verl",
     "SinkFlashAttentionFunc",
+    "sink_decode_attention_ring",
+    "SinkCacheLayer",
+    "SinkAttentionCache",
 ]

@@ -57,6 +57,8 @@ def _bind(lib):
     lib.sfa_decode_workspace_bytes.argtypes = [i64, i64, i64, i64, i64, i32]
     lib.sfa_decode.restype = i32
     lib.sfa_decode.argtypes = [P, P, P, P, vp, vp, sz, f32, u32, vp]
+    lib.sfa_decode_ring.restype = i32
+    lib.sfa_decode_ring.argtypes = [P, P, P, i64, P, P, i64, P, vp, vp, sz, f32, u32, vp]
 
 
 def lib():

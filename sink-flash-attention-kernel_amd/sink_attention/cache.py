@@ -1,0 +1,191 @@
+"""Sink + sliding-window KV cache for decode, with a copy-free attention path.
+
+Same observable behaviour as the reference's ``sink_attention/cache.py`` (``SinkCacheLayer`` :29-238,
+``SinkAttentionCache`` :241-330): a fixed sink buffer ``[B, H_kv, num_sink, D]`` plus a circular window buffer
+``[B, H_kv, window_size, D]``; prefill stores the state and hands the full K/V back (the prefill kernel masks),
+a decode step overwrites one ring slot.  ``update()`` / ``get_kv()`` still return the linearised ``[sink, window]``
+tensors for callers that want them, but attention itself no longer needs them:
+
+    layer.append(k_new, v_new)                       # one slot written, no torch.cat
+    out = layer.decode_attention(q, s_aux=sinks)     # sfa_decode_ring reads sink buffer + ring in place
+
+The reference rebuilds ``[B, H_kv, ns+W, D]`` with up to three ``torch.cat`` per step and measures that copy as
+costly as the attention itself (its README, "cache update + decode").  Bookkeeping is host-side Python on torch
+tensors and works on any device; ``decode_attention`` needs the HIP library.
+"""
+from abc import ABC
+from typing import List, Optional, Tuple
+
+import torch
+
+try:  # the HF base classes are optional, exactly as in the reference (cache.py:20-26)
+    from transformers.cache_utils import Cache as _HFCache, CacheLayerMixin as _HFLayer
+    _HAS_HF = True
+except ImportError:  # pragma: no cover
+    _HAS_HF = False
+    _HFCache = object
+    _HFLayer = ABC
+
+
+class SinkCacheLayer(_HFLayer if _HAS_HF else object):
+    """One layer's cache: ``num_sink`` pinned leading tokens + a ring of the last ``window_size`` others."""
+
+    def __init__(self, num_sink: int, window_size: int):
+        if _HAS_HF:
+            super().__init__()
+        self.num_sink = int(num_sink)
+        self.window_size = int(window_size)
+        self.sink_k = self.sink_v = self.window_k = self.window_v = None
+        self.sink_len = 0        # valid rows of the sink buffer
+        self.window_len = 0      # valid slots of the ring
+        self.write_pos = 0       # ring slot the next decoded token goes to
+        self.prefilled = False
+        self.seen_tokens = 0
+        self.is_initialized = False
+
+    # ------------------------------------------------------------------ state
+    def lazy_initialization(self, key_states: torch.Tensor, *_, **__):
+        B, H_kv, _n, D = key_states.shape
+        mk = lambda n: torch.zeros(B, H_kv, n, D, dtype=key_states.dtype, device=key_states.device)
+        self.sink_k, self.sink_v = mk(self.num_sink), mk(self.num_sink)
+        self.window_k, self.window_v = mk(self.window_size), mk(self.window_size)
+        self.is_initialized = True
+
+    def _prefill(self, k, v):
+        N = k.shape[2]
+        self.seen_tokens = N
+        ns = min(N, self.num_sink)
+        self.sink_k[:, :, :ns] = k[:, :, :ns]
+        self.sink_v[:, :, :ns] = v[:, :, :ns]
+        self.sink_len = ns
+        rest = N - ns
+        if rest <= 0:
+            self.window_len, self.write_pos = 0, 0
+        elif rest <= self.window_size:
+            self.window_k[:, :, :rest] = k[:, :, ns:]
+            self.window_v[:, :, :rest] = v[:, :, ns:]
+            self.window_len = rest
+            self.write_pos = rest % self.window_size
+        else:   # keep only the newest window_size tokens; the ring is full and wraps at slot 0
+            self.window_k.copy_(k[:, :, N - self.window_size:])
+            self.window_v.copy_(v[:, :, N - self.window_size:])
+            self.window_len, self.write_pos = self.window_size, 0
+        self.prefilled = True
+        return k, v
+
+    def append(self, k: torch.Tensor, v: torch.Tensor) -> None:
+        """Write decoded token(s) ``[B, H_kv, n, D]`` into the ring (oldest evicted).  No linearisation."""
+        if not self.is_initialized:
+            self.lazy_initialization(k)
+        if not self.prefilled:      # first tokens ever: same placement as a prefill (sinks first)
+            self._prefill(k, v)
+            return
+        for i in range(k.shape[2]):
+            self.seen_tokens += 1
+            if self.window_size > 0:
+                self.window_k[:, :, self.write_pos] = k[:, :, i]
+                self.window_v[:, :, self.write_pos] = v[:, :, i]
+                self.write_pos = (self.write_pos + 1) % self.window_size
+                self.window_len = min(self.window_len + 1, self.window_size)
+        self.prefilled = True
+
+    def update(self, key_states, value_states, cache_kwargs: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Reference-compatible update: prefill returns the full input K/V, decode returns linearised [sink, window]."""
+        if not self.is_initialized:
+            self.lazy_initialization(key_states)
+        if not self.prefilled:
+            return self._prefill(key_states, value_states)
+        self.append(key_states, value_states)
+        return self.get_kv()
+
+    def get_kv(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Chronological ``[B, H_kv, sink_len + window_len, D]`` copy (oldest first) - only for callers that need it."""
+        ks, vs = [self.sink_k[:, :, :self.sink_len]], [self.sink_v[:, :, :self.sink_len]]
+        if self.window_len > 0:
+            if self.window_len < self.window_size or self.write_pos == 0:
+                ks.append(self.window_k[:, :, :self.window_len])
+                vs.append(self.window_v[:, :, :self.window_len])
+            else:
+                ks += [self.window_k[:, :, self.write_pos:], self.window_k[:, :, :self.write_pos]]
+                vs += [self.window_v[:, :, self.write_pos:], self.window_v[:, :, :self.write_pos]]
+        return torch.cat(ks, dim=2), torch.cat(vs, dim=2)
+
+    # -------------------------------------------------------------- attention
+    def decode_attention(self, q: torch.Tensor, s_aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Single-query attention of ``q [B, H_q, 1, D]`` over the cached keys, reading both buffers in place."""
+        from .decode_kernel import sink_decode_attention_ring
+        return sink_decode_attention_ring(q, self.sink_k, self.sink_v, self.sink_len, self.window_k, self.window_v,
+                                          self.window_len, s_aux=s_aux)
+
+    # ------------------------------------------------------- HF layer surface
+    def get_seq_length(self, *_, **__) -> int:
+        return self.sink_len + self.window_len
+
+    def get_mask_sizes(self, cache_position, *_, **__) -> Tuple[int, int]:
+        return self.get_seq_length(), 0
+
+    def get_max_cache_shape(self) -> int:
+        return self.num_sink + self.window_size
+
+    def get_max_length(self) -> int:   # abstract in transformers >= 5 (the reference predates it)
+        return self.num_sink + self.window_size
+
+    def reorder_cache(self, beam_idx: torch.LongTensor):
+        if self.sink_k is None:
+            return
+        idx = beam_idx.to(self.sink_k.device)
+        self.sink_k, self.sink_v = self.sink_k.index_select(0, idx), self.sink_v.index_select(0, idx)
+        self.window_k, self.window_v = self.window_k.index_select(0, idx), self.window_v.index_select(0, idx)
+
+
+class SinkAttentionCache(_HFCache if _HAS_HF else object):
+    """Per-layer ``SinkCacheLayer``s behind the transformers ``Cache`` interface (layers created on first use)."""
+
+    def __init__(self, num_sink: int = 4, window_size: int = 4096):
+        self.num_sink, self.window_size = num_sink, window_size
+        self._seen_tokens = 0
+        if _HAS_HF:
+            super().__init__(layer_class_to_replicate=None, layers=[])
+        else:  # pragma: no cover
+            self.layers: List[SinkCacheLayer] = []
+
+    def __len__(self):
+        return len(self.layers)
+
+    def __getitem__(self, idx):
+        return self.layers[idx]
+
+    def __repr__(self):
+        return (f"SinkAttentionCache(num_sink={self.num_sink}, window_size={self.window_size}, "
+                f"layers={len(self.layers)}, seen_tokens={self._seen_tokens})")
+
+    def _layer(self, layer_idx: int) -> SinkCacheLayer:
+        while len(self.layers) <= layer_idx:
+            self.layers.append(SinkCacheLayer(self.num_sink, self.window_size))
+        return self.layers[layer_idx]
+
+    def update(self, key_states, value_states, layer_idx: int, cache_kwargs: Optional[dict] = None):
+        out = self._layer(layer_idx).update(key_states, value_states, cache_kwargs)
+        if layer_idx == 0:
+            self._seen_tokens = self.layers[0].seen_tokens
+        return out
+
+    def append(self, key_states, value_states, layer_idx: int) -> None:
+        """Copy-free decode update of one layer (pair with ``self[layer_idx].decode_attention``)."""
+        self._layer(layer_idx).append(key_states, value_states)
+        if layer_idx == 0:
+            self._seen_tokens = self.layers[0].seen_tokens
+
+    def get_seq_length(self, layer_idx: int = 0, *_, **__) -> int:
+        return self.layers[layer_idx].get_seq_length() if layer_idx < len(self.layers) else 0
+
+    def get_max_cache_length(self) -> int:
+        return self.num_sink + self.window_size
+
+    def reorder_cache(self, beam_idx):
+        for layer in self.layers:
+            layer.reorder_cache(beam_idx)
+
+    @property
+    def seen_tokens(self) -> int:
+        return self._seen_tokens

@@ -52,3 +52,55 @@ def sink_decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                             scale, 0, N.stream_ptr(q.device))
     N.check(st, "sfa_decode")
     return out
+
+
+def sink_decode_attention_ring(q: torch.Tensor, sink_k: torch.Tensor, sink_v: torch.Tensor, sink_len: int,
+                               window_k: torch.Tensor, window_v: torch.Tensor, window_len: int,
+                               s_aux: torch.Tensor = None) -> torch.Tensor:
+    """Decode over a sink buffer + window ring WITHOUT linearising them (``sfa_decode_ring``).
+
+    Equivalent to ``sink_decode_attention(q, cat(sink_k[:, :, :sink_len], ring in any order), ...)`` - softmax does
+    not depend on key order - but reads both cache buffers in place; replaces the ``torch.cat`` copies of the
+    reference's ``SinkCacheLayer.get_kv`` (cache.py:185-216).
+        q [B,H_q,1,D]; sink_k/v [B,H_kv,num_sink,D] (first ``sink_len`` rows valid);
+        window_k/v [B,H_kv,window_size,D] (first ``window_len`` slots valid; all of them once the ring is full).
+    """
+    N.require_gpu(q, sink_k, sink_v, window_k, window_v, s_aux)
+    B, H_q, N_q, D = q.shape
+    H_kv = sink_k.shape[1]
+    assert N_q == 1, f"sink_decode_attention requires N_q=1, got {N_q}"
+    assert H_q % H_kv == 0, f"H_q ({H_q}) must be divisible by H_kv ({H_kv})"
+    assert sink_v.shape == sink_k.shape and window_v.shape == window_k.shape
+    assert window_k.shape[:2] == sink_k.shape[:2] and window_k.shape[3] == D and sink_k.shape[3] == D
+    assert 0 <= sink_len <= sink_k.shape[2] and 0 <= window_len <= window_k.shape[2]
+    for t in (sink_k, sink_v, window_k, window_v):
+        if t.dtype != q.dtype:
+            raise TypeError("q and the cache buffers must share one dtype")
+    if q.dtype not in N.SFA_DTYPE:
+        raise TypeError(f"unsupported dtype {q.dtype}")
+    row_bytes = D * q.element_size()
+    assert row_bytes % 16 == 0 and row_bytes <= 1024, f"D={D}: a K/V row must be a multiple of 16 bytes, <= 1 KiB"
+
+    def rows16(t):
+        t = N.unit_inner(t.detach())
+        es = t.element_size()
+        if t.numel() and (t.data_ptr() % 16 or any((t.stride(i) * es) % 16 for i in range(3))):
+            t = t.contiguous()
+        return t
+
+    q, sink_k, sink_v, window_k, window_v = (rows16(t) for t in (q, sink_k, sink_v, window_k, window_v))
+    s_aux_f = None
+    if s_aux is not None:
+        assert s_aux.shape == (H_q,), f"s_aux shape must be [H_q={H_q}], got {s_aux.shape}"
+        s_aux_f = s_aux.detach().contiguous().float()
+    out = torch.empty((B, H_q, 1, D), device=q.device, dtype=q.dtype)
+    lib = N.lib()
+    ws_bytes = lib.sfa_decode_workspace_bytes(B, H_q, H_kv, int(sink_len) + int(window_len), D, N.SFA_DTYPE[q.dtype])
+    ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)
+    with torch.cuda.device(q.device):
+        st = lib.sfa_decode_ring(N.desc(q), N.desc(sink_k), N.desc(sink_v), int(sink_len), N.desc(window_k),
+                                 N.desc(window_v), int(window_len), N.desc(out),
+                                 s_aux_f.data_ptr() if s_aux_f is not None else None, ws.data_ptr(), ws.numel(),
+                                 1.0 / math.sqrt(D), 0, N.stream_ptr(q.device))
+    N.check(st, "sfa_decode_ring")
+    return out

@@ -198,6 +198,38 @@ def main():
                                _is_packed(pid_len1), _is_packed(None)], dtype=np.int64))
 
 
+def cache_cases():
+    """F8: the reference's SinkCacheLayer driven through prefill + decode steps:
+    bookkeeping after every step and the linearised K/V it hands to the decode kernel."""
+    from sink_attention.cache import SinkCacheLayer
+    # the reference class predates transformers 5.x's abstract CacheLayerMixin.get_max_length and cannot be
+    # instantiated against the installed transformers; clearing the abstract set does not touch its logic
+    SinkCacheLayer.__abstractmethods__ = frozenset()
+    for name, ns, W, prefill, steps, seed in [("f8_cache_evict", 2, 3, 4, 10, 80), ("f8_cache_short_prefill", 4, 8, 2, 6, 81),
+                                              ("f8_cache_overflow", 4, 8, 16, 5, 82), ("f8_cache_exact", 3, 5, 8, 7, 83)]:
+        g = torch.Generator().manual_seed(seed)
+        Ntot = prefill + steps
+        k_all, v_all = rnd((1, 2, Ntot, 8), g), rnd((1, 2, Ntot, 8), g)
+        layer = SinkCacheLayer(ns, W)
+        res = dict(k_all=k_all, v_all=v_all, meta=np.array([ns, W, prefill, steps, seed], dtype=np.int64))
+        state = []
+        ko, vo = layer.update(k_all[:, :, :prefill], v_all[:, :, :prefill])
+        state.append([layer.sink_len, layer.window_len, layer.write_pos, layer.seen_tokens, ko.shape[2]])
+        lk, lv = layer.get_kv()
+        res["k_lin_0"], res["v_lin_0"] = lk.clone(), lv.clone()
+        for i in range(steps):
+            pos = prefill + i
+            ko, vo = layer.update(k_all[:, :, pos:pos + 1], v_all[:, :, pos:pos + 1])
+            state.append([layer.sink_len, layer.window_len, layer.write_pos, layer.seen_tokens, ko.shape[2]])
+            res[f"k_lin_{i + 1}"], res[f"v_lin_{i + 1}"] = ko.clone(), vo.clone()
+        res["state"] = np.array(state, dtype=np.int64)
+        npz(name, **res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cache":
+        cache_cases()
+    else:
+        main()
+        cache_cases()

@@ -149,3 +149,52 @@ def test_baseline_c5_slice():
     out = _op()(q, k, v)
     ref = O.decode_dense(q.cpu(), k.cpu(), v.cpu())
     assert_close(out, ref.bfloat16(), 2e-2, 2e-2, "C5 slice")
+
+
+# ---- decode over the sink buffer + window ring in place (sfa_decode_ring)
+@pytest.mark.parametrize("dtype,Hq,Hkv,D,ns,W,prefill,steps", [
+    (torch.float32, 4, 4, 64, 4, 8, 11, 14),       # wraps the ring several times (tests/test_inference.py:157-199)
+    (torch.bfloat16, 8, 2, 128, 4, 64, 100, 40),   # GQA, ring full from the prefill on
+    (torch.float16, 8, 8, 128, 2, 300, 5, 30),     # ring never fills
+    (torch.bfloat16, 16, 2, 80, 0, 33, 50, 10),    # no sink buffer rows at all, D = 80, s_aux
+])
+def test_ring_decode_equals_linearised_decode_and_oracle(dtype, Hq, Hkv, D, ns, W, prefill, steps):
+    from sink_attention import SinkCacheLayer, sink_decode_attention
+    g = torch.Generator().manual_seed(21)
+    Ntot = prefill + steps
+    q = rand((1, Hq, Ntot, D), g, dtype)
+    k, v = rand((1, Hkv, Ntot, D), g, dtype), rand((1, Hkv, Ntot, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.7) if ns == 0 else None
+    layer = SinkCacheLayer(ns, W)
+    layer.append(k[:, :, :prefill].to(DEV), v[:, :, :prefill].to(DEV))
+    tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    for pos in range(prefill, Ntot):
+        layer.append(k[:, :, pos:pos + 1].to(DEV), v[:, :, pos:pos + 1].to(DEV))
+        qd = q[:, :, pos:pos + 1].to(DEV)
+        out = layer.decode_attention(qd, s_aux=None if sa is None else sa.to(DEV))
+        from sink_attention import _native
+        assert "ring" in _native.last_path()
+        # (1) same as the reference flow: linearise with get_kv(), then the plain decode
+        kl, vl = layer.get_kv()
+        assert maxdiff(out, sink_decode_attention(qd, kl, vl, s_aux=None if sa is None else sa.to(DEV))) < tol
+        # (2) the CPU oracle on the keys the cache policy keeps
+        keep = torch.tensor(sorted(set(range(min(ns, pos + 1))) | set(range(max(ns, pos - W + 1), pos + 1))))
+        ref = O.decode_dense(q[:, :, pos:pos + 1], k[:, :, keep], v[:, :, keep], sa)
+        assert maxdiff(out, ref) < tol, pos
+
+
+def test_ring_decode_c5_policy_shape():
+    """BASELINE config 5 with its cache policy: B=32, H=32, D=128, num_sink=4, window=4096 -> 4100 keys per step."""
+    from sink_attention import SinkCacheLayer
+    B, H, D, ns, W = 32, 32, 128, 4, 4096
+    g = torch.Generator().manual_seed(5)
+    k, v = rand((B, H, ns + W + 7, D), g, torch.bfloat16), rand((B, H, ns + W + 7, D), g, torch.bfloat16)
+    q = rand((B, H, 1, D), g, torch.bfloat16)
+    layer = SinkCacheLayer(ns, W)
+    layer.append(k[:, :, :ns + W].to(DEV), v[:, :, :ns + W].to(DEV))
+    for i in range(7):
+        layer.append(k[:, :, ns + W + i:ns + W + i + 1].to(DEV), v[:, :, ns + W + i:ns + W + i + 1].to(DEV))
+    out = layer.decode_attention(q.to(DEV))
+    keep = torch.tensor(list(range(ns)) + list(range(ns + 7, ns + W + 7)))
+    ref = O.decode_dense(q[:4], k[:4][:, :, keep], v[:4][:, :, keep])
+    assert_close(out[:4], ref.bfloat16(), 1e-2, 1e-2, "C5 policy")
