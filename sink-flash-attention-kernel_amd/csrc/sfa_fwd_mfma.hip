@@ -57,6 +57,7 @@ struct FwdArgs {
     int hpw, rb;           // q heads per workgroup, 32-row blocks per workgroup (hpw * rb == NW)
     int n_qtiles, hgroups;
     unsigned q_range, k_range, v_range, o_range;  // byte extent of one (b, head) slice
+    int prio;              // tuning knob (SFA_FWD_PRIO): raised priority for waves 4..7
 };
 
 __device__ __forceinline__ float half_swap_max(float x) {
@@ -192,6 +193,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     const float c = a.scale_log2;
+    // waves 4..7 are dispatched second and lose VALU/MFMA arbitration to their SIMD partners by age (measured with
+    // s_memtime stamps: they set the tile time while waves 0..3 idle at the barrier); optional static priority raise
+    if (NW == 8 && a.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     if (nt > 0) {
         issue_loads(tile_of(0));
@@ -386,6 +390,10 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.rb = NW / a.hpw;
     a.n_qtiles = (int)cdiv64(p.N, 32 * a.rb);
     a.hgroups = g / a.hpw;
+    {
+        const char* e = getenv("SFA_FWD_PRIO");
+        a.prio = e ? atoi(e) : 1;
+    }
     a.q_range = slice_range(q); a.k_range = slice_range(k); a.v_range = slice_range(v); a.o_range = slice_range(o);
     const int64_t nblk = (int64_t)a.n_qtiles * a.hgroups * p.Hkv * p.B;
     if (nblk >= (1ll << 31)) {
