@@ -13,6 +13,7 @@ views and the output is produced directly in [B,N,H,D] memory (the reference mak
 transpose+contiguous copies per call, :119-126,:164-177); ``unpatch_verl`` resets the saved
 original so a later re-patch works (the reference leaves it set, making re-patching a no-op).
 """
+import os
 from typing import Optional
 
 import torch
@@ -21,6 +22,11 @@ from .decode_kernel import sink_decode_attention
 from .sink_flash_attention import _sink_flash_attention_ex
 
 _original_flash_attention_forward = None
+
+# SURVEY section 8 f-3.  False (default) = the reference's behaviour: packed / varlen calls go back to the original
+# flash attention, which drops s_aux.  True (or env SINK_ATTENTION_VARLEN=1) = run every packed sequence through the
+# sink attention kernels (sink_attention.varlen) so s_aux and the per-layer window are honoured there too.
+ENABLE_VARLEN = os.environ.get("SINK_ATTENTION_VARLEN", "0") == "1"
 
 
 def _local_s_aux(s_aux, H_q):
@@ -77,6 +83,19 @@ def _sink_flash_attention_forward(
 
     varlen = all(x is not None for x in (cu_seq_lens_q, cu_seq_lens_k, max_length_q, max_length_k))
     packed = position_ids is not None and query_states.size(0) > 0 and _is_packed(position_ids)
+    if (ENABLE_VARLEN and (varlen or packed) and is_causal and attention_mask is None and softcap is None
+            and query_states.shape[0] == 1 and query_states.shape[1] == key_states.shape[1]):
+        from .varlen import seq_bounds_from_position_ids, sink_flash_attention_varlen
+        if varlen:
+            cu = cu_seq_lens_q.tolist()
+        else:
+            cu = seq_bounds_from_position_ids(position_ids[0] if position_ids.dim() > 1 else position_ids)
+        T = query_states.shape[1]
+        out = sink_flash_attention_varlen(query_states.transpose(1, 2), key_states.transpose(1, 2),
+                                          value_states.transpose(1, 2), cu, num_sink=0,
+                                          window_size=sliding_window if sliding_window is not None else T,
+                                          s_aux=_local_s_aux(s_aux, query_states.shape[2]))
+        return out.transpose(1, 2).contiguous()
     if varlen or packed or not is_causal or attention_mask is not None or softcap is not None:
         if s_aux is not None:
             kwargs["s_aux"] = s_aux

@@ -147,3 +147,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libsfa.so"))
     with pytest.raises(RuntimeError, match="no Python/CPU fallback"):
         _native.lib()
+
+
+def test_varlen_bounds_and_default_fallback():
+    from sink_attention.varlen import seq_bounds_from_position_ids
+    import sink_attention.verl_patch as vp
+    pid = torch.tensor([0, 1, 2, 0, 1, 0, 1, 2, 3])
+    assert seq_bounds_from_position_ids(pid) == [0, 3, 5, 9]
+    assert seq_bounds_from_position_ids(torch.arange(4)) == [0, 4]
+    assert vp.ENABLE_VARLEN is False          # default = the reference's fallback behaviour for packed batches
