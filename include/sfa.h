@@ -53,6 +53,11 @@ extern "C" {
 
 /* flags */
 #define SFA_FLAG_FORCE_GENERIC 0x1u /* use the exact-f32 generic kernels even when an MFMA kernel exists */
+/* sfa_bwd / sfa_bwd_workspace_bytes: trade workspace for recompute.  The dK/dV kernel saves dS (16 bit, 2 bytes
+ * per valid (query, key) pair per q head) in the workspace and dQ becomes a plain GEMM over it instead of a second
+ * recompute of S and dP.  The workspace query reports the larger size; pass the SAME flags to both calls.  Ignored
+ * (no extra workspace) where the MFMA backward does not apply. */
+#define SFA_FLAG_BWD_SPILL_DS 0x2u
 
 typedef struct sfa_tensor {
     void* ptr;         /* device pointer to element [0,0,0,0]                    */

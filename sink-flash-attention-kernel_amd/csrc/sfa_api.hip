@@ -89,7 +89,7 @@ struct BwdWorkspace {
     size_t delta_off, dsaux_off, mfma_off, total;
 };
 
-BwdWorkspace bwd_layout(const Problem& p, int dtype, bool use_mfma) {
+BwdWorkspace bwd_layout(const Problem& p, int dtype, bool use_mfma, unsigned flags) {
     BwdWorkspace w;
     size_t off = 0;
     w.delta_off = off;
@@ -97,7 +97,7 @@ BwdWorkspace bwd_layout(const Problem& p, int dtype, bool use_mfma) {
     w.dsaux_off = off;
     off += align256((size_t)p.B * p.Hq * (size_t)bwd_preprocess_nblk(p.N) * sizeof(float));
     w.mfma_off = off;
-    if (use_mfma) off += align256(bwd_mfma_workspace_bytes(p, dtype));
+    if (use_mfma) off += align256(bwd_mfma_workspace_bytes(p, dtype, flags));
     w.total = off;
     return w;
 }
@@ -138,7 +138,7 @@ size_t sfa_bwd_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t N, in
                                int window, unsigned flags) {
     Problem p{(int)B, (int)Hq, (int)Hkv, (int)N, (int)D, num_sink, window, 1.f};
     const bool use_mfma = !(flags & SFA_FLAG_FORCE_GENERIC) && bwd_mfma_supported(dtype, (int)D);
-    return bwd_layout(p, dtype, use_mfma).total;
+    return bwd_layout(p, dtype, use_mfma, flags).total;
 }
 
 int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
@@ -159,7 +159,7 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     SFA_CHECK_ARG(lse != nullptr, "lse: null pointer");
     SFA_CHECK_ARG((s_aux == nullptr) == (ds_aux == nullptr), "ds_aux must be given iff s_aux is");
     const bool use_mfma = !(flags & SFA_FLAG_FORCE_GENERIC) && bwd_mfma_supported(q->dtype, p.D);
-    const BwdWorkspace w = bwd_layout(p, q->dtype, use_mfma);
+    const BwdWorkspace w = bwd_layout(p, q->dtype, use_mfma, flags);
     if (workspace == nullptr || workspace_bytes < w.total || ((uintptr_t)workspace & 255) != 0) {
         set_error("bwd workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", w.total, workspace_bytes,
                   workspace);
@@ -173,7 +173,7 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     record_stage(1, s);
     if (st) return st;
     if (use_mfma)
-        st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, s);
+        st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, flags, s);
     else
         st = bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, s);
     record_stage(3, s);

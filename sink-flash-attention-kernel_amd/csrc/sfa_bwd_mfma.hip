@@ -81,7 +81,33 @@ struct BwdArgs {
     int n_kblocks;               // dK/dV kernel: ceil(N / 128)
     int hpw, rb, n_qtiles, hgroups;  // dQ kernel
     int prio;                        // experiment knob: score-wave priority in the wave-specialised dK/dV kernel
+    // dS spill (SFA_FLAG_BWD_SPILL_DS): the dK/dV kernel saves dS (16 bit) per (head, key block, 32-row slice) and dQ
+    // becomes a plain GEMM over it.  Chunk (kb, qt) of a head lives at ds + (head_idx * ds_chunks + ds_prefix[kb] +
+    // qt - 4*kb) * kDsChunk
+    char* ds;
+    const int* ds_prefix;            // [n_kblocks + 1] exclusive prefix of slices per key block
+    int ds_nt;                       // tuning knob (SFA_DS_NT): non-temporal hint on the dS stream loads of the dQ GEMM
+    int64_t ds_chunks;               // chunks per head = ds_prefix[n_kblocks]
 };
+
+constexpr int kDsChunk = 32 * 128 * 2;   // bytes of one dS chunk: 32 query rows x 128 keys x 16 bit
+
+// query slices (32 rows) that the 128-key block kb must sweep: [4*kb, 4*kb + nq)
+__host__ __device__ inline int dkdv_slices(int kb, int N, int ns, int W) {
+    const int kb0 = kb * 128;
+    const int kb1 = (kb0 + 128 < N) ? kb0 + 128 : N;
+    int i_hi;
+    if (kb0 < ns) {
+        i_hi = N;
+    } else {
+        i_hi = kb1 - 1 + W;
+        if (i_hi > N) i_hi = N;
+    }
+    const int qt_lo = kb0 / 32;
+    int qt_hi = (i_hi + 31) / 32;
+    if (qt_hi < qt_lo) qt_hi = qt_lo;
+    return qt_hi - qt_lo;
+}
 
 // One LDS image serves row reads (ds_read_b128 MFMA operand) and transposed reads (ds_read_b64_tr_b16):
 // XOR the 16-byte chunk index with sw(row).  256-byte rows: 16 chunks; 128-byte rows (D <= 64): 8 chunks.
@@ -918,7 +944,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel_p(BwdArgs a) {
 // Loop hygiene (measured with s_memtime stamps, tools/stamps.py): no integer division in the loop (slice
 // coordinates advance incrementally), descriptors rebuilt only when the q head changes, trips unrolled x4 so
 // the stage offset of every ds_read is an immediate, per-lane swizzled offsets hoisted.
-template <typename T, int D>
+template <typename T, int D, bool SPILL>
 __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     using M = Mma<T>;
     using frag = typename M::frag;
@@ -964,7 +990,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const int qt_lo = kb0 / QT;
     int qt_hi = (i_hi + QT - 1) / QT;
     if (qt_hi < qt_lo) qt_hi = qt_lo;
-    const int nq = qt_hi - qt_lo;
+    const int nq = qt_hi - qt_lo;          // == dkdv_slices(kb, N, ns, W)
     const int n_it = g * nq;
 
     // ---- slice loader: ONLY the accumulate waves stage slices (they idle at the barrier; on the score waves the
@@ -1023,11 +1049,16 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
 
     // end of a trip: on the loader waves everything but the DMAs just issued (2*NDW, +1 on wave 4) must have
     // landed; exchange writes / fragment reads done
-    auto trip_sync = [&](bool more) {
+    // (dS spill: the accumulate wave's two dS stores of this trip, issued after the DMAs, may stay in flight too)
+    auto trip_sync = [&](bool more, bool stored = false) {
         if (!acc_role || !more)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (lw == 0 && stored)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDW + 3) : "memory");
         else if (lw == 0)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDW + 1) : "memory");
+        else if (stored)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDW + 2) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDW) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -1156,7 +1187,6 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
         auto trip = [&](auto ktag, int t) {
             constexpr int K = decltype(ktag)::value;
             STAMP(7)
-            if (t + 3 < n_it) stage_next(((K + 3) % NST) * STAGE);
             STAMP(0)
             if (t < n_it) {
                 const bool full = (kw0 + 31 <= q0) && (q0 + 31 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 31));
@@ -1213,6 +1243,17 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
             ta2[db] = smem_base + (unsigned)((tr_row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row + 8)) << 4) + tr_byte);
         }
         const char* xr = xch + kg * XBYTES + lane * 16;
+        // dS spill: the accumulate wave (it has the slack) also saves the dS fragments it reads from the exchange:
+        // per key group 2 KB = [pS index s2][lane][16 B], so each store instruction writes 1 KB contiguous
+        char* dsp = nullptr;
+        int64_t ds_head_step = 0;
+        int ac_q = 0;                 // slices accumulated for the current head
+        u32x4 sv0 = {0, 0, 0, 0}, sv1 = {0, 0, 0, 0};
+        if constexpr (SPILL) {
+            dsp = a.ds + (((int64_t)b * a.Hq + (int64_t)hk * g) * a.ds_chunks + a.ds_prefix[kb]) * kDsChunk + kg * 2048 +
+                  lane * 16;
+            ds_head_step = (a.ds_chunks - nq) * (int64_t)kDsChunk;
+        }
         // transposed fragments of the slice to accumulate next (asm reads issued one trip ahead, see tr_read_asm;
         // they are waited for by the lgkmcnt(0) of trip_sync)
         s16x4 dlo[2][DVB], dhi[2][DVB], qlo[2][DVB], qhi[2][DVB];
@@ -1250,6 +1291,10 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
                 pS[0] = *reinterpret_cast<const frag*>(x + 2048);
                 pS[1] = *reinterpret_cast<const frag*>(x + 3072);
                 STAMP(1)
+                if constexpr (SPILL) {
+                    sv0 = __builtin_bit_cast(u32x4, pS[0]);
+                    sv1 = __builtin_bit_cast(u32x4, pS[1]);
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1263,7 +1308,18 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
                 __builtin_amdgcn_sched_barrier(0);   // the asm reads overwrite the fragments: MFMAs above must be issued first
                 prefetch(ktag);
             }
-            trip_sync(t + 3 < n_it);
+            if constexpr (SPILL) {
+                if (t >= 1) {   // after the MFMAs and the read burst: the store issue hides under the LDS latency
+                    __builtin_nontemporal_store(sv0, reinterpret_cast<u32x4*>(dsp));
+                    __builtin_nontemporal_store(sv1, reinterpret_cast<u32x4*>(dsp + 1024));
+                    dsp += kDsChunk;
+                    if (++ac_q == nq) {
+                        ac_q = 0;
+                        dsp += ds_head_step;
+                    }
+                }
+            }
+            trip_sync(t + 3 < n_it, SPILL && t >= 1);
             STAMP(5)
         };
         int t = 0;
@@ -1518,6 +1574,270 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
         }
 }
 
+// =============================================================== dQ from spilled dS (plain GEMM, HBM-bound)
+// dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i] over the dS chunks the dK/dV kernel saved: no S / dP recompute.
+// Workgroup = 8 compute waves = 8 consecutive 32-row slices of one (b, q head) + 1 LOADER wave.  A stage = 64 keys.
+//   * The K half tile is shared: the loader wave brings it by LDS-DMA into a KR-deep ring (swizzled image, K^T
+//     fragments by transposed reads) one stage ahead and signals it with the workgroup barrier.
+//   * Each compute wave streams ITS OWN dS (4 KB per stage) into a private R-deep ring, R-1 stages in flight, gated
+//     only by its own counted vmcnt (vmcnt retires in order, so the deep dS stream must not share a wave with the
+//     shallow K stream: that is why K has its own wave).  The stream from HBM (2 bytes per (query, key) pair and
+//     head) is what bounds the kernel; ~100 KB in flight per CU cover the ~3.5 us loaded latency.
+//   * The dS image in LDS is [key][64 B], gathered by the DMA from the stored fragments ([key group][sigma = 2 s2 +
+//     h][key][16 B], written by the dK/dV kernel with 1 KB-contiguous stores): a transposed read turns it into the
+//     B operand, its N index being the STORED row order, undone at the dQ store.
+//   * A slice that a key block does not cover has no chunk: its offset falls outside the block's descriptor range
+//     and the DMA zero-fills.
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+template <typename T, int D, int R, int KR>
+__global__ __launch_bounds__(576, 1) void bwd_dq_gemm_kernel(BwdArgs a) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    using E = typename M::elem;
+    constexpr int NW = 8;
+    constexpr int DVB = (D + 31) / 32;
+    constexpr int CPR = D / 8;
+    constexpr int ROWB = (D <= 64) ? 128 : 256;
+    constexpr int SPR = ROWB / 16;                   // 16-byte slots per K row
+    constexpr int KBYTES = 64 * ROWB;                // K half tile
+    constexpr int DSOFF = KR * KBYTES;               // dS rings start here: [wave][slot][4096]
+    constexpr int NDK = (64 * SPR) / 64;             // K DMA instructions per stage (loader wave)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nqb = (a.N + 32 * NW - 1) / (32 * NW);
+    const int qb = bid % nqb;
+    const int bh = bid / nqb;
+    const int head = bh % a.Hq, b = bh / a.Hq;
+    const int g = a.Hq / a.Hkv;
+    const int hk = head / g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int N = a.N, W = a.window, ns = a.num_sink;
+    const int q0 = qb * 32 * NW;                       // first row of the workgroup
+    const int q_last = (q0 + 32 * NW < N ? q0 + 32 * NW : N) - 1;
+
+    // key blocks to visit: sink blocks [0, nsb) then window blocks [kb_lo, kb_hi]
+    const int kb_hi = q_last / kKB;
+    int nsb = (ns + kKB - 1) / kKB;
+    if (nsb > kb_hi + 1) nsb = kb_hi + 1;
+    int wlo = q0 - W + 1;
+    if (wlo < 0) wlo = 0;
+    int kb_lo = wlo / kKB;
+    if (kb_lo < nsb) kb_lo = nsb;
+    const int n_blocks = nsb + (kb_hi >= kb_lo ? kb_hi - kb_lo + 1 : 0);
+    const int n_st = 2 * n_blocks;                     // stages (64 keys each)
+    auto block_of = [&](int i) { return i < nsb ? i : kb_lo + (i - nsb); };
+
+    if (wave == NW) {
+        // ------------------------------------------------------------------ loader wave: the K ring
+        const char* kbase = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, a.k_range, 0x00020000);
+        const unsigned ksn2 = (unsigned)(a.k.sn * 2);
+        unsigned vk0[NDK];     // LDS slot c = 64 i + lane -> (row, slot); source chunk = slot ^ sw(row)
+#pragma unroll
+        for (int i = 0; i < NDK; ++i) {
+            const int cidx = i * 64 + lane;
+            const int row = cidx / SPR;
+            const int ch = (cidx % SPR) ^ sw<ROWB>(row);
+            vk0[i] = ch < CPR ? (unsigned)row * ksn2 + (unsigned)(ch * 16) : 0xFFFFFFF0u;
+        }
+        auto issue_k = [&](int st, int buf_off) {
+            const unsigned key0 = (unsigned)(block_of(st >> 1) * kKB + (st & 1) * 64);
+#pragma unroll
+            for (int i = 0; i < NDK; ++i) {
+                const unsigned ko = vk0[i] == 0xFFFFFFF0u ? vk0[i] : vk0[i] + key0 * ksn2;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + buf_off + i * 1024),
+                                                         16, ko, 0, 0, 0);
+            }
+        };
+        if (n_st > 0) issue_k(0, 0);
+        int kbuf = 0;
+        for (int st = 0; st < n_st; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K(st) landed
+            __builtin_amdgcn_s_barrier();                          // ... and every reader of K(st + 1 - KR) is done
+            __builtin_amdgcn_sched_barrier(0);
+            kbuf = kbuf + 1 == KR ? 0 : kbuf + 1;
+            if (st + 1 < n_st) issue_k(st + 1, kbuf * KBYTES);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int qt = qb * NW + wave;                     // this wave's slice
+    const char* dsh = a.ds + ((int64_t)b * a.Hq + head) * a.ds_chunks * kDsChunk;
+    char* ring = smem + DSOFF + wave * (R * 4096);
+    int pf_next = n_st > 0 ? a.ds_prefix[block_of(0)] : 0;
+    int nq_next = n_st > 0 ? a.ds_prefix[block_of(0) + 1] - pf_next : 0;
+    const unsigned so_lane = (unsigned)((lane & 3) * 512 + (lane >> 2) * 16);
+    auto issue_ds = [&](int st, int slot_off) {
+        const int kb = block_of(st >> 1), half = st & 1;
+        // descriptor = the block's chunk range of this head, so a slice the block does not cover reads zeros
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(dsh + (int64_t)pf_next * kDsChunk), 0, (unsigned)nq_next * (unsigned)kDsChunk, 0x00020000);
+        // LDS slot c = 64 i + lane -> key 16 (i & 1) + lane / 4 of key group i / 2, sigma = lane % 4
+        const unsigned so = (unsigned)(qt - 4 * kb) * (unsigned)kDsChunk + (unsigned)(half * 4096) + so_lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            auto dst = (__attribute__((address_space(3))) void*)(ring + slot_off + i * 1024);
+            const unsigned o = so + (unsigned)((i >> 1) * 2048 + (i & 1) * 256);
+            if (a.ds_nt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, dst, 16, o, 0, 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, dst, 16, o, 0, 0, 0);
+        }
+        if (half == 1 && st + 1 < n_st) {              // next block's table entries, one stage ahead of their use
+            const int kn = block_of((st + 1) >> 1);
+            pf_next = a.ds_prefix[kn];
+            nq_next = a.ds_prefix[kn + 1] - pf_next;
+        }
+    };
+
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int tr_row = 4 * h + q4;
+    const int tr_col = 2 * g1 + (p4 >> 1);
+    const int tr_byte = (p4 & 1) * 8;
+    const unsigned smem_base = (unsigned)(size_t)smem;
+    unsigned ta1[DVB], ta2[DVB];
+#pragma unroll
+    for (int db = 0; db < DVB; ++db) {
+        ta1[db] = smem_base + (unsigned)(tr_row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row)) << 4) + tr_byte);
+        ta2[db] = smem_base + (unsigned)((tr_row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(tr_row + 8)) << 4) + tr_byte);
+    }
+    const unsigned tb = smem_base + (unsigned)(DSOFF + wave * (R * 4096) + tr_row * 64 + tr_col * 16 + tr_byte);
+
+    f32x16 dQt[DVB];
+#pragma unroll
+    for (int db = 0; db < DVB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQt[db][i] = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i)
+        if (i < n_st) issue_ds(i, i * 4096);
+
+    // stage st (st % R == K): own dS(st) landed (counted), barrier (K(st) landed), refill the ring slot freed by
+    // stage st-1, transposed reads, 16 MFMAs
+    auto stage = [&](auto ktag, auto kbtag, int st) {
+        constexpr int K = decltype(ktag)::value;
+        constexpr unsigned KOFF = decltype(kbtag)::value * KBYTES;
+        constexpr unsigned SOFF = K * 4096;
+        const int ahead = n_st - 1 - st < R - 2 ? n_st - 1 - st : R - 2;   // own dS stages younger than st in flight
+        if (ahead >= 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + R - 1 < n_st) issue_ds(st + R - 1, ((K + R - 1) % R) * 4096);
+        s16x4 blo[2][2], bhi[2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            blo[kh][0] = tr_read_asm<0>(tb + SOFF + kh * 2048);
+            bhi[kh][0] = tr_read_asm<512>(tb + SOFF + kh * 2048);
+            blo[kh][1] = tr_read_asm<1024>(tb + SOFF + kh * 2048);
+            bhi[kh][1] = tr_read_asm<1536>(tb + SOFF + kh * 2048);
+        }
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            s16x4 alo[2][DVB], ahi[2][DVB];
+#pragma unroll
+            for (int db = 0; db < DVB; ++db) {
+                alo[0][db] = tr_read_asm<0>(ta1[db] + KOFF + kh * 32 * ROWB);
+                ahi[0][db] = tr_read_asm<0>(ta2[db] + KOFF + kh * 32 * ROWB);
+                alo[1][db] = tr_read_asm<16 * ROWB>(ta1[db] + KOFF + kh * 32 * ROWB);
+                ahi[1][db] = tr_read_asm<16 * ROWB>(ta2[db] + KOFF + kh * 32 * ROWB);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < DVB; ++db)
+                    dQt[db] = M::run(__builtin_bit_cast(frag, join8(alo[s2][db], ahi[s2][db])),
+                                     __builtin_bit_cast(frag, join8(blo[kh][s2], bhi[kh][s2])), dQt[db]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert(R == 4 || R == 3, "ring depth");
+    static_assert(R % KR == 0, "the unrolled stage index must determine the K buffer");
+    int st = 0;
+    if constexpr (R == 4) {
+        for (; st + 4 <= n_st; st += 4) {
+            stage(IC<0>{}, IC<0 % KR>{}, st);
+            stage(IC<1>{}, IC<1 % KR>{}, st + 1);
+            stage(IC<2>{}, IC<2 % KR>{}, st + 2);
+            stage(IC<3>{}, IC<3 % KR>{}, st + 3);
+        }
+        if (st < n_st) stage(IC<0>{}, IC<0 % KR>{}, st++);
+        if (st < n_st) stage(IC<1>{}, IC<1 % KR>{}, st++);
+        if (st < n_st) stage(IC<2>{}, IC<2 % KR>{}, st++);
+    } else {
+        for (; st + 3 <= n_st; st += 3) {
+            stage(IC<0>{}, IC<0 % KR>{}, st);
+            stage(IC<1>{}, IC<1 % KR>{}, st + 1);
+            stage(IC<2>{}, IC<2 % KR>{}, st + 2);
+        }
+        if (st < n_st) stage(IC<0>{}, IC<0 % KR>{}, st++);
+        if (st < n_st) stage(IC<1>{}, IC<1 % KR>{}, st++);
+    }
+
+    // dQ = scale * dQ^T^T; accumulator column n = 8*sigma + pos = 16 s2 + 8 h' + 4 qb + e holds row
+    // 16 s2 + 8 qb + 4 h' + e of the slice (bits 2 and 3 of n swapped)
+    const int n = lane & 31;
+    const int qrow = qt * 32 + (n & 19) + ((n & 4) << 1) + ((n & 8) >> 1);
+    char* dqb = a.dq.ptr + ((int64_t)b * a.dq.sb + (int64_t)head * a.dq.sh) * 2;
+    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void*)dqb, 0, a.dq_range, 0x00020000);
+    const unsigned orow = (unsigned)qrow * (unsigned)(a.dq.sn * 2);
+    typedef __attribute__((ext_vector_type(4))) E e4;
+#pragma unroll
+    for (int db = 0; db < DVB; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 32 * db + 8 * g4 + 4 * h;
+            if (d < D) {
+                e4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (E)(dQt[db][4 * g4 + e] * a.scale);
+                const unsigned off = qrow < N ? orow + (unsigned)(d * 2) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rdq, off, 0, 0);
+            }
+        }
+}
+
+// exclusive prefix of dkdv_slices() over the key blocks: the chunk index table of the dS spill
+__global__ __launch_bounds__(256) void ds_prefix_kernel(int* __restrict__ tbl, int n_kb, int N, int ns, int W) {
+    __shared__ int part[256];
+    const int t = threadIdx.x;
+    const int per = (n_kb + 255) / 256;
+    const int lo = t * per < n_kb ? t * per : n_kb;
+    const int hi = lo + per < n_kb ? lo + per : n_kb;
+    int sum = 0;
+    for (int kb = lo; kb < hi; ++kb) sum += dkdv_slices(kb, N, ns, W);
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int x = part[i];
+            part[i] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int kb = lo; kb < hi; ++kb) {
+        tbl[kb] = run;
+        run += dkdv_slices(kb, N, ns, W);
+    }
+    if (hi == n_kb && (lo < hi || t == 0)) tbl[n_kb] = run;
+}
+
 // row constants for the wave-specialised dK/dV kernel: consts[b,h,0,:] = -LSE*log2e, consts[b,h,1,:] = -Delta
 __global__ __launch_bounds__(256) void bwd_consts_kernel(const float* __restrict__ lse, const float* __restrict__ delta,
                                                         float* __restrict__ consts, int N, int64_t total) {
@@ -1530,16 +1850,32 @@ __global__ __launch_bounds__(256) void bwd_consts_kernel(const float* __restrict
 }
 
 // ==================================================================== launch
+int dkdv_mode() {
+    static const int mode = [] {
+        const char* e = getenv("SFA_DKDV");
+        return e ? atoi(e) : 3;
+    }();
+    return mode;
+}
+
+// dS spill geometry: chunks per head (0 = spill not possible for this problem)
+int64_t ds_chunks_per_head(const Problem& p) {
+    const int W = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);
+    const int n_kb = (int)cdiv64(p.N, kKB);
+    int64_t total = 0;
+    for (int kb = 0; kb < n_kb; ++kb) total += dkdv_slices(kb, p.N, p.num_sink, W);
+    if (total * kDsChunk >= (1ll << 31)) return 0;   // 32-bit offsets inside one head's chunk range
+    return total;
+}
+size_t ds_table_bytes(const Problem& p) { return (((size_t)cdiv64(p.N, kKB) + 1) * sizeof(int) + 255) & ~(size_t)255; }
+
 template <typename T, int D>
 int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
     constexpr int ROWB = (D <= 64) ? 128 : 256;
     // dK/dV variant (C3, ms): 3 = wave-specialised score/accumulate waves, 2 per SIMD (default, 4.1);
     // 0 = 4 waves, one per SIMD (5.0); 1 = 8 identical waves with K/V from LDS (LDS-bound, 7.4);
     // 2 = 4 waves software-pipelined (register-starved under hipcc 7.2, 6.8)
-    static const int mode = [] {
-        const char* e = getenv("SFA_DKDV");
-        return e ? atoi(e) : 3;
-    }();
+    const int mode = dkdv_mode();
     const int use_w8 = mode == 1;
     if (mode == 3) {
         {
@@ -1548,13 +1884,55 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
                 a.lse, a.delta, const_cast<float*>(a.consts), a.N, total);
         }
         constexpr int lds = 4 * (2 * 32 * ROWB + 256) + 2 * 4 * 4096;
-        auto kern = bwd_dkdv_mfma_kernel_ws<T, D>;
+        const int nblk = a.n_kblocks * a.Hkv * B;
+        if (a.ds) {
+            // dS spill: chunk table, dK/dV kernel that also saves dS, then dQ as a GEMM over the saved dS
+            ds_prefix_kernel<<<dim3(1), dim3(256), 0, stream>>>(const_cast<int*>(a.ds_prefix), a.n_kblocks, a.N,
+                                                                a.num_sink, a.window);
+            auto kern = bwd_dkdv_mfma_kernel_ws<T, D, true>;
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done = true;
+            }
+            kern<<<dim3(nblk), dim3(512), lds, stream>>>(a);
+            int st = launch_status("bwd_dkdv_mfma_ws_spill");
+            if (st) return st;
+            record_stage(2, stream);
+            static const int gr = [] {      // dS ring depth of the dQ GEMM: 4 (160 KB LDS) or 3 (144 KB)
+                const char* e = getenv("SFA_DQ_GEMM_R");
+                return e && atoi(e) == 3 ? 3 : 4;
+            }();
+            const int64_t gblk = (int64_t)B * a.Hq * cdiv64(a.N, 32 * 8);
+            if (gr == 4) {
+                constexpr int glds = 2 * 64 * ROWB + 8 * 4 * 4096;
+                auto gk = bwd_dq_gemm_kernel<T, D, 4, 2>;
+                static bool gdone = false;
+                if (!gdone) {
+                    (void)hipFuncSetAttribute((const void*)gk, hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+                    gdone = true;
+                }
+                gk<<<dim3((unsigned)gblk), dim3(576), glds, stream>>>(a);
+            } else {
+                constexpr int glds = 3 * 64 * ROWB + 8 * 3 * 4096;
+                auto gk = bwd_dq_gemm_kernel<T, D, 3, 3>;
+                static bool gdone = false;
+                if (!gdone) {
+                    (void)hipFuncSetAttribute((const void*)gk, hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+                    gdone = true;
+                }
+                gk<<<dim3((unsigned)gblk), dim3(576), glds, stream>>>(a);
+            }
+            const int gnw = gr;
+            set_path("bwd_mfma_%s_d%d_dkdvws8_spill_dqgemm_r%d", DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, gnw);
+            return launch_status("bwd_dq_gemm");
+        }
+        auto kern = bwd_dkdv_mfma_kernel_ws<T, D, false>;
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             done = true;
         }
-        const int nblk = a.n_kblocks * a.Hkv * B;
         kern<<<dim3(nblk), dim3(512), lds, stream>>>(a);
         int st = launch_status("bwd_dkdv_mfma_ws");
         if (st) return st;
@@ -1639,11 +2017,22 @@ bool bwd_mfma_supported(int dtype, int D) {
     return (dtype == SFA_DTYPE_BF16 || dtype == SFA_DTYPE_F16) && (D == 64 || D == 80 || D == 96 || D == 128);
 }
 
-size_t bwd_mfma_workspace_bytes(const Problem& p, int) { return (size_t)p.B * p.Hq * p.N * 2 * sizeof(float); }
+static size_t consts_bytes(const Problem& p) { return ((size_t)p.B * p.Hq * p.N * 2 * sizeof(float) + 255) & ~(size_t)255; }
+
+bool bwd_mfma_spill(const Problem& p, unsigned flags) {
+    return (flags & SFA_FLAG_BWD_SPILL_DS) && dkdv_mode() == 3 && ds_chunks_per_head(p) > 0;
+}
+
+size_t bwd_mfma_workspace_bytes(const Problem& p, int, unsigned flags) {
+    size_t n = consts_bytes(p);
+    if (bwd_mfma_spill(p, flags))
+        n += ds_table_bytes(p) + (size_t)p.B * p.Hq * (size_t)ds_chunks_per_head(p) * kDsChunk;
+    return n;
+}
 
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o, const float* lse,
              const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void* workspace,
-             const Problem& p, hipStream_t stream) {
+             const Problem& p, unsigned flags, hipStream_t stream) {
     if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(d_o) && slice_ok(dq) && slice_ok(dk) && slice_ok(dv)))
         return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, stream);
     const int g = p.Hq / p.Hkv;
@@ -1652,6 +2041,18 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.dq = make_view(dq); a.dk = make_view(dk); a.dv = make_view(dv);
     a.lse = lse; a.delta = delta;
     a.consts = reinterpret_cast<const float*>(workspace);
+    a.ds = nullptr;
+    a.ds_prefix = nullptr;
+    a.ds_chunks = 0;
+    if (bwd_mfma_spill(p, flags)) {
+        a.ds_prefix = reinterpret_cast<const int*>((char*)workspace + consts_bytes(p));
+        a.ds = (char*)workspace + consts_bytes(p) + ds_table_bytes(p);
+        a.ds_chunks = ds_chunks_per_head(p);
+    }
+    {
+        const char* e = getenv("SFA_DS_NT");
+        a.ds_nt = e ? atoi(e) : 1;
+    }
     a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
     a.num_sink = p.num_sink;
     a.window = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);

@@ -21,10 +21,10 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
 
 // sfa_bwd_mfma.hip
 bool bwd_mfma_supported(int dtype, int D);
-size_t bwd_mfma_workspace_bytes(const Problem& p, int dtype);
+size_t bwd_mfma_workspace_bytes(const Problem& p, int dtype, unsigned flags);
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
              const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,
-             const sfa_tensor* dv, void* workspace, const Problem& p, hipStream_t stream);
+             const sfa_tensor* dv, void* workspace, const Problem& p, unsigned flags, hipStream_t stream);
 
 // sfa_decode.hip
 struct DecodePlan {

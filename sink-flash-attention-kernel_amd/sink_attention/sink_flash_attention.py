@@ -18,10 +18,17 @@ Differences from the reference (all inside its tolerances / a superset of its su
   * Delta and ds_aux come from one HIP preprocess pass (the reference: eager ops :582,:658-665).
 """
 import math
+import os
 
 import torch
 
 from . import _native as N
+
+
+def _ds_spill_cap_bytes() -> int:
+    """Largest extra backward workspace (bytes) the op may take to save dS for the dQ GEMM (SFA_FLAG_BWD_SPILL_DS)
+    instead of recomputing S and dP in the dQ kernel.  Env SINK_ATTENTION_DS_SPILL_GB (float, 0 disables)."""
+    return int(float(os.environ.get("SINK_ATTENTION_DS_SPILL_GB", N.DS_SPILL_DEFAULT_GB)) * (1 << 30))
 
 
 class SinkFlashAttentionFunc(torch.autograd.Function):
@@ -78,14 +85,20 @@ class SinkFlashAttentionFunc(torch.autograd.Function):
         dv = torch.empty((B, H_kv, Nq, D), device=q.device, dtype=q.dtype)
         ds_aux = torch.empty((H_q,), device=q.device, dtype=torch.float32) if ctx.use_s_aux else None
         lib = N.lib()
-        ws_bytes = lib.sfa_bwd_workspace_bytes(B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink,
-                                               ctx.window_size, ctx.flags)
+        flags = ctx.flags
+        ws_args = (B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink, ctx.window_size)
+        ws_bytes = lib.sfa_bwd_workspace_bytes(*ws_args, flags)
+        cap = _ds_spill_cap_bytes()
+        if cap > 0 and not (flags & N.FLAG_FORCE_GENERIC):
+            spill_bytes = lib.sfa_bwd_workspace_bytes(*ws_args, flags | N.FLAG_BWD_SPILL_DS)
+            if ws_bytes < spill_bytes <= ws_bytes + cap:
+                flags, ws_bytes = flags | N.FLAG_BWD_SPILL_DS, spill_bytes
         ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)
         with torch.cuda.device(q.device):
             st = lib.sfa_bwd(N.desc(q), N.desc(k), N.desc(v), N.desc(o), N.desc(do), lse.data_ptr(),
                              s_aux_f.data_ptr() if ctx.use_s_aux else None, N.desc(dq), N.desc(dk), N.desc(dv),
                              ds_aux.data_ptr() if ctx.use_s_aux else None, ws.data_ptr(), ws.numel(),
-                             ctx.num_sink, ctx.window_size, ctx.scale, ctx.flags, N.stream_ptr(q.device))
+                             ctx.num_sink, ctx.window_size, ctx.scale, flags, N.stream_ptr(q.device))
         N.check(st, "sfa_bwd")
         if ctx.use_s_aux and ds_aux.dtype != ctx.s_aux_dtype:
             ds_aux = ds_aux.to(ctx.s_aux_dtype)
