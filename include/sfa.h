@@ -115,6 +115,29 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
             void* stream);
 
 /*
+ * Packed (variable-length) batches, SURVEY.md section 8 f-3.  The reference cannot do this: its boundary hands packed
+ * batches back to stock flash attention, which drops s_aux (sink_attention/verl_patch.py:73-93).
+ *   q,o,do,dq [1, Hq, T, D]   k,v,dk,dv [1, Hkv, T, D]   lse [Hq, T] float32
+ *   cu_seqlens: DEVICE int32 [n_seq + 1], cu[0] = 0, cu[n_seq] = T; sequence i = rows cu[i] .. cu[i+1].  Every
+ *   sequence gets its own mask origin (valid(i, j) in its own positions) and its own s_aux term.
+ *   max_seqlen: longest sequence (only sizes the grids; an upper bound is fine).
+ *   Workspace of sfa_bwd_varlen: sfa_bwd_workspace_bytes(1, Hq, Hkv, T, D, dtype, num_sink, window, 0).
+ * 16-bit dtypes and head dims 64 / 80 / 96 / 128 only (sfa_varlen_supported); SFA_ERR_UNSUPPORTED otherwise - the
+ * caller can then run the sequences one by one through sfa_fwd / sfa_bwd on strided views.
+ */
+int sfa_varlen_supported(int dtype, int64_t D);
+
+int sfa_fwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
+                   const float* s_aux, const int32_t* cu_seqlens, int n_seq, int max_seqlen, int num_sink,
+                   int window, float scale, unsigned flags, void* stream);
+
+int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+                   const sfa_tensor* d_o, const float* lse, const float* s_aux, const sfa_tensor* dq,
+                   const sfa_tensor* dk, const sfa_tensor* dv, float* ds_aux, const int32_t* cu_seqlens, int n_seq,
+                   int max_seqlen, void* workspace, size_t workspace_bytes, int num_sink, int window, float scale,
+                   unsigned flags, void* stream);
+
+/*
  * Single-query decode over every key handed in (no mask; windowing is the cache's job,
  * decode_kernel.py:72-83).
  *   q,o [B, Hq, 1, D]   k,v [B, Hkv, Nkv, D]   s_aux nullable [Hq] float32

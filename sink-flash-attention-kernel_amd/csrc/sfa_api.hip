@@ -180,6 +180,81 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     return st;
 }
 
+int sfa_varlen_supported(int dtype, int64_t D) {
+    return fwd_mfma_supported(dtype, (int)D) && bwd_mfma_supported(dtype, (int)D) ? 1 : 0;
+}
+
+// shared checks of the packed entry points; on success *p describes the packed tensors (B = 1, N = total rows) and
+// *run the launch (B = n_seq, N = max_seqlen, cu set)
+static int check_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const int32_t* cu, int n_seq,
+                        int max_seqlen, int num_sink, int window, float scale, Problem* p, Problem* run) {
+    int st = check_prefill(q, k, v, p, num_sink, window, scale);
+    if (st) return st;
+    SFA_CHECK_ARG(p->B == 1, "packed layout: batch dim must be 1 (got %d)", p->B);
+    SFA_CHECK_ARG(cu != nullptr && n_seq >= 1, "cu_seqlens: need a device array of n_seq + 1 >= 2 offsets");
+    SFA_CHECK_ARG(max_seqlen >= 1 && max_seqlen <= p->N, "max_seqlen %d out of range (total rows %d)", max_seqlen, p->N);
+    if (!sfa_varlen_supported(q->dtype, p->D)) {
+        set_error("packed (varlen) kernels exist for 16-bit dtypes and head dims 64/80/96/128 only");
+        return SFA_ERR_UNSUPPORTED;
+    }
+    *run = *p;
+    run->B = n_seq;
+    run->N = max_seqlen;
+    run->cu = cu;
+    run->n_total = p->N;
+    return SFA_OK;
+}
+
+int sfa_fwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
+                   const float* s_aux, const int32_t* cu_seqlens, int n_seq, int max_seqlen, int num_sink, int window,
+                   float scale, unsigned flags, void* stream) {
+    g_err[0] = 0;
+    (void)flags;
+    Problem p, run;
+    int st = check_varlen(q, k, v, cu_seqlens, n_seq, max_seqlen, num_sink, window, scale, &p, &run);
+    if (st) return st;
+    if ((st = check_tensor(o, "o")) || (st = same_shape(q, o, "q", "o"))) return st;
+    if (p.Hq == 0 || p.N == 0) return SFA_OK;
+    SFA_CHECK_ARG(lse != nullptr, "lse: null pointer");
+    return fwd_mfma(q, k, v, o, lse, s_aux, run, (hipStream_t)stream);
+}
+
+int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
+                   const sfa_tensor* d_o, const float* lse, const float* s_aux, const sfa_tensor* dq,
+                   const sfa_tensor* dk, const sfa_tensor* dv, float* ds_aux, const int32_t* cu_seqlens, int n_seq,
+                   int max_seqlen, void* workspace, size_t workspace_bytes, int num_sink, int window, float scale,
+                   unsigned flags, void* stream) {
+    g_err[0] = 0;
+    (void)flags;
+    Problem p, run;
+    int st = check_varlen(q, k, v, cu_seqlens, n_seq, max_seqlen, num_sink, window, scale, &p, &run);
+    if (st) return st;
+    if ((st = check_tensor(o, "o")) || (st = same_shape(q, o, "q", "o"))) return st;
+    if ((st = check_tensor(d_o, "do")) || (st = same_shape(q, d_o, "q", "do"))) return st;
+    if ((st = check_tensor(dq, "dq")) || (st = same_shape(q, dq, "q", "dq"))) return st;
+    if ((st = check_tensor(dk, "dk")) || (st = same_shape(k, dk, "k", "dk"))) return st;
+    if ((st = check_tensor(dv, "dv")) || (st = same_shape(v, dv, "v", "dv"))) return st;
+    if (p.Hq == 0 || p.N == 0) return SFA_OK;
+    SFA_CHECK_ARG(lse != nullptr, "lse: null pointer");
+    SFA_CHECK_ARG((s_aux == nullptr) == (ds_aux == nullptr), "ds_aux must be given iff s_aux is");
+    const BwdWorkspace w = bwd_layout(p, q->dtype, true, 0);      // same carving as sfa_bwd with B = 1, N = total rows
+    if (workspace == nullptr || workspace_bytes < w.total || ((uintptr_t)workspace & 255) != 0) {
+        set_error("bwd workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", w.total, workspace_bytes,
+                  workspace);
+        return SFA_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* delta = reinterpret_cast<float*>((char*)workspace + w.delta_off);
+    float* dsaux_part = reinterpret_cast<float*>((char*)workspace + w.dsaux_off);
+    record_stage(0, s);
+    st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s);   // row-wise: no sequence structure
+    record_stage(1, s);
+    if (st) return st;
+    st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, run, 0, s);
+    record_stage(3, s);
+    return st;
+}
+
 size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype) {
     DecodePlan pl;
     if (decode_plan(B, Hq, Hkv, Nkv, D, dtype, &pl) != SFA_OK) return 0;

@@ -86,6 +86,8 @@ struct BwdArgs {
     // qt - 4*kb) * kDsChunk
     char* ds;
     const int* ds_prefix;            // [n_kblocks + 1] exclusive prefix of slices per key block
+    const int* cu;                   // packed batches: device row offsets [B + 1] (else null), see Problem
+    int n_total;                     // rows of the packed tensors
     int ds_nt;                       // tuning knob (SFA_DS_NT): non-temporal hint on the dS stream loads of the dQ GEMM
     int64_t ds_chunks;               // chunks per head = ds_prefix[n_kblocks]
 };
@@ -973,9 +975,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const int kg = wave & 3;
     const bool acc_role = wave >= 4;
     const int r = lane & 31, h = lane >> 5;
-    const int N = a.N, W = a.window, ns = a.num_sink;
+    const SeqInfo sq = seq_of(a.cu, b, a.N);
+    const int N = sq.N, ns = a.num_sink;
+    const int W = a.window < N ? a.window : N;
+    const int NT_ = a.cu ? a.n_total : N;      // rows of one head in the [B, Hq, 2, rows] row-constant buffer
     const int g = a.Hq / a.Hkv;
     const int kb0 = kb * kKB;
+    if (kb0 >= N) return;                      // packed batches: the grid is sized for the longest sequence
     const int kb1 = (kb0 + kKB < N) ? kb0 + kKB : N;
     const int kw0 = kb0 + 32 * kg;
     const int key = kw0 + r;
@@ -1011,15 +1017,16 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const unsigned qstep = (unsigned)(QT * a.q.sn * 2), dstep = (unsigned)(QT * a.d_o.sn * 2);
     int ld_hh = 0, ld_qt = qt_lo;
     __amdgpu_buffer_rsrc_t rq, rdo, rc;
-    const unsigned voc0 = (unsigned)((lane < 32 ? 0 : N) + (lane & 31)) * 4u;   // wave 4: -LSE*log2e | -Delta rows
+    const unsigned voc0 = (unsigned)((lane < 32 ? 0 : NT_) + (lane & 31)) * 4u;   // wave 4: -LSE*log2e | -Delta rows
+    const unsigned q_rng = seq_range(a.cu, a.q_range, N, a.q.sn, D), do_rng = seq_range(a.cu, a.do_range, N, a.d_o.sn, D);
     auto set_head = [&](int hh) {
         const int head = hk * g + hh;
-        const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
-        const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
-        rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
-        rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
-        rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.consts + ((int64_t)b * a.Hq + head) * 2 * N), 0,
-                                               (unsigned)(2 * N * 4), 0x00020000);
+        const char* qb = a.q.ptr + ((int64_t)sq.bb * a.q.sb + (int64_t)head * a.q.sh + (int64_t)sq.row0 * a.q.sn) * 2;
+        const char* dob = a.d_o.ptr + ((int64_t)sq.bb * a.d_o.sb + (int64_t)head * a.d_o.sh + (int64_t)sq.row0 * a.d_o.sn) * 2;
+        rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, q_rng, 0x00020000);
+        rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, do_rng, 0x00020000);
+        rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.consts + ((int64_t)sq.bb * a.Hq + head) * 2 * NT_ + sq.row0), 0,
+                                               (unsigned)((2 * NT_ - sq.row0) * 4), 0x00020000);
     };
     auto stage_next = [&](int stage_off) {     // stage_off = byte offset of the destination stage (compile-time at call sites)
         if (!acc_role) return;
@@ -1077,10 +1084,10 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
         // the score wave is the critical path of a trip: let it win MFMA/VALU arbitration on its SIMD so the
         // accumulate wave's MFMAs fill its exp/pack phase instead of delaying its S/dP chain
         if (a.prio) __builtin_amdgcn_s_setprio(2);
-        const char* kbase = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
-        const char* vbase = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
-        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, a.k_range, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, a.v_range, 0x00020000);
+        const char* kbase = a.k.ptr + ((int64_t)sq.bb * a.k.sb + (int64_t)hk * a.k.sh + (int64_t)sq.row0 * a.k.sn) * 2;
+        const char* vbase = a.v.ptr + ((int64_t)sq.bb * a.v.sb + (int64_t)hk * a.v.sh + (int64_t)sq.row0 * a.v.sn) * 2;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, seq_range(a.cu, a.k_range, N, a.k.sn, D), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, seq_range(a.cu, a.v_range, N, a.v.sn, D), 0x00020000);
         frag kf[DK], vf[DK];
 #pragma unroll
         for (int ks = 0; ks < DK; ++ks) {
@@ -1339,10 +1346,10 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
         }
 #endif
 
-        char* dkb = a.dk.ptr + ((int64_t)b * a.dk.sb + (int64_t)hk * a.dk.sh) * 2;
-        char* dvb = a.dv.ptr + ((int64_t)b * a.dv.sb + (int64_t)hk * a.dv.sh) * 2;
-        const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, a.dk_range, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, a.dv_range, 0x00020000);
+        char* dkb = a.dk.ptr + ((int64_t)sq.bb * a.dk.sb + (int64_t)hk * a.dk.sh + (int64_t)sq.row0 * a.dk.sn) * 2;
+        char* dvb = a.dv.ptr + ((int64_t)sq.bb * a.dv.sb + (int64_t)hk * a.dv.sh + (int64_t)sq.row0 * a.dv.sn) * 2;
+        const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, seq_range(a.cu, a.dk_range, N, a.dk.sn, D), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, seq_range(a.cu, a.dv_range, N, a.dv.sn, D), 0x00020000);
         typedef __attribute__((ext_vector_type(4))) E e4;
 #pragma unroll
         for (int db = 0; db < DVB; ++db)
@@ -1395,9 +1402,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
     const int g = a.Hq / a.Hkv;
     const int hh = wave % a.hpw, rbi = wave / a.hpw;
     const int head = hk * g + hg * a.hpw + hh;
-    const int N = a.N, W = a.window, ns = a.num_sink;
+    const SeqInfo sq = seq_of(a.cu, b, a.N);
+    const int N = sq.N, ns = a.num_sink;
+    const int W = a.window < N ? a.window : N;
     const int BM = 32 * a.rb;
     const int q0 = qt * BM;
+    if (q0 >= N) return;   // packed batches: the grid is sized for the longest sequence
     const int q1 = (q0 + BM < N) ? q0 + BM : N;
     const int qw0 = q0 + 32 * rbi;
     const int qw_hi = (qw0 + 31 < N - 1) ? qw0 + 31 : N - 1;
@@ -1414,16 +1424,16 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
     if (tw_lo > tw_hi) tw_lo = tw_hi;
     const int nt = ts_hi + (tw_hi - tw_lo);
 
-    const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
-    const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
-    const char* kb = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
-    const char* vb = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
-    char* dqb = a.dq.ptr + ((int64_t)b * a.dq.sb + (int64_t)head * a.dq.sh) * 2;
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, a.k_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, a.v_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void*)dqb, 0, a.dq_range, 0x00020000);
+    const char* qb = a.q.ptr + ((int64_t)sq.bb * a.q.sb + (int64_t)head * a.q.sh + (int64_t)sq.row0 * a.q.sn) * 2;
+    const char* dob = a.d_o.ptr + ((int64_t)sq.bb * a.d_o.sb + (int64_t)head * a.d_o.sh + (int64_t)sq.row0 * a.d_o.sn) * 2;
+    const char* kb = a.k.ptr + ((int64_t)sq.bb * a.k.sb + (int64_t)hk * a.k.sh + (int64_t)sq.row0 * a.k.sn) * 2;
+    const char* vb = a.v.ptr + ((int64_t)sq.bb * a.v.sb + (int64_t)hk * a.v.sh + (int64_t)sq.row0 * a.v.sn) * 2;
+    char* dqb = a.dq.ptr + ((int64_t)sq.bb * a.dq.sb + (int64_t)head * a.dq.sh + (int64_t)sq.row0 * a.dq.sn) * 2;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, seq_range(a.cu, a.q_range, N, a.q.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, seq_range(a.cu, a.do_range, N, a.d_o.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, seq_range(a.cu, a.k_range, N, a.k.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, seq_range(a.cu, a.v_range, N, a.v.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void*)dqb, 0, seq_range(a.cu, a.dq_range, N, a.dq.sn, D), 0x00020000);
 
     frag qf[DK], dof[DK];
 #pragma unroll
@@ -1435,7 +1445,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
     }
     float lse2 = INFINITY, dlt = 0.f;   // rows >= N: p = exp2(-inf) = 0
     if (qrow < N) {
-        const int64_t idx = ((int64_t)b * a.Hq + head) * N + qrow;
+        const int64_t idx = (a.cu ? (int64_t)head * a.n_total + sq.row0 : ((int64_t)b * a.Hq + head) * N) + qrow;
         lse2 = a.lse[idx] * kLog2e;
         dlt = a.delta[idx];
     }
@@ -1879,9 +1889,10 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
     const int use_w8 = mode == 1;
     if (mode == 3) {
         {
-            const int64_t total = (int64_t)B * a.Hq * a.N;
+            const int rows = a.cu ? a.n_total : a.N;                  // packed batches: one [Hq, n_total] slab
+            const int64_t total = (a.cu ? 1 : (int64_t)B) * a.Hq * rows;
             bwd_consts_kernel<<<dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream>>>(
-                a.lse, a.delta, const_cast<float*>(a.consts), a.N, total);
+                a.lse, a.delta, const_cast<float*>(a.consts), rows, total);
         }
         constexpr int lds = 4 * (2 * 32 * ROWB + 256) + 2 * 4 * 4096;
         const int nblk = a.n_kblocks * a.Hkv * B;
@@ -2017,11 +2028,17 @@ bool bwd_mfma_supported(int dtype, int D) {
     return (dtype == SFA_DTYPE_BF16 || dtype == SFA_DTYPE_F16) && (D == 64 || D == 80 || D == 96 || D == 128);
 }
 
-static size_t consts_bytes(const Problem& p) { return ((size_t)p.B * p.Hq * p.N * 2 * sizeof(float) + 255) & ~(size_t)255; }
+static size_t consts_bytes(const Problem& p) {
+    const size_t rows = p.cu ? (size_t)p.n_total : (size_t)p.B * p.N;
+    return (rows * p.Hq * 2 * sizeof(float) + 255) & ~(size_t)255;
+}
 
 bool bwd_mfma_spill(const Problem& p, unsigned flags) {
-    return (flags & SFA_FLAG_BWD_SPILL_DS) && dkdv_mode() == 3 && ds_chunks_per_head(p) > 0;
+    return (flags & SFA_FLAG_BWD_SPILL_DS) && dkdv_mode() == 3 && p.cu == nullptr && ds_chunks_per_head(p) > 0;
 }
+
+// packed batches are served by the default (wave-specialised) dK/dV kernel only
+bool bwd_mfma_varlen_ok() { return dkdv_mode() == 3; }
 
 size_t bwd_mfma_workspace_bytes(const Problem& p, int, unsigned flags) {
     size_t n = consts_bytes(p);
@@ -2033,14 +2050,25 @@ size_t bwd_mfma_workspace_bytes(const Problem& p, int, unsigned flags) {
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o, const float* lse,
              const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void* workspace,
              const Problem& p, unsigned flags, hipStream_t stream) {
-    if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(d_o) && slice_ok(dq) && slice_ok(dk) && slice_ok(dv)))
+    if (p.cu && !bwd_mfma_varlen_ok()) {
+        set_error("packed (varlen) backward is served by the default dK/dV kernel only (SFA_DKDV=3)");
+        return SFA_ERR_UNSUPPORTED;
+    }
+    if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(d_o) && slice_ok(dq) && slice_ok(dk) && slice_ok(dv))) {
+        if (p.cu) {
+            set_error("packed (varlen) backward needs 16-byte aligned rows and < 4 GiB head slices");
+            return SFA_ERR_UNSUPPORTED;
+        }
         return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, stream);
+    }
     const int g = p.Hq / p.Hkv;
     BwdArgs a;
     a.q = make_view(q); a.k = make_view(k); a.v = make_view(v); a.d_o = make_view(d_o);
     a.dq = make_view(dq); a.dk = make_view(dk); a.dv = make_view(dv);
     a.lse = lse; a.delta = delta;
     a.consts = reinterpret_cast<const float*>(workspace);
+    a.cu = p.cu;
+    a.n_total = p.n_total;
     a.ds = nullptr;
     a.ds_prefix = nullptr;
     a.ds_chunks = 0;

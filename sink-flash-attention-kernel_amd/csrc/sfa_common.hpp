@@ -45,12 +45,36 @@ inline View make_view(const sfa_tensor* t) {
     return View{(char*)t->ptr, t->stride[0], t->stride[1], t->stride[2]};
 }
 
-// Problem description shared by the prefill kernels.
+// Problem description shared by the prefill kernels.  Packed (varlen) batches: cu != nullptr is a DEVICE array of
+// n_seq + 1 row offsets into tensors of shape [1, H, n_total, D]; B = n_seq and N = the longest sequence then only
+// size the grids, every workgroup takes its own (first row, length) from cu.
 struct Problem {
     int B, Hq, Hkv, N, D;
     int num_sink, window;
     float scale;
+    const int* cu = nullptr;
+    int n_total = 0;
 };
+
+#ifdef __HIPCC__
+struct SeqInfo {
+    int N;      // rows of this workgroup's sequence
+    int row0;   // its first row inside the (b, head) slice
+    int bb;     // batch index for pointer arithmetic
+};
+__device__ __forceinline__ SeqInfo seq_of(const int* cu, int b, int N) {
+    if (cu) {
+        const int r0 = cu[b];
+        return SeqInfo{cu[b + 1] - r0, r0, 0};
+    }
+    return SeqInfo{N, 0, b};
+}
+// byte extent of one sequence's rows of a (b, head) slice: the buffer descriptor range, so that rows >= N read zero
+// and stores to them are dropped (a packed neighbour starts right there)
+__device__ __forceinline__ unsigned seq_range(const int* cu, unsigned whole, int N, int64_t sn, int D) {
+    return cu ? (unsigned)((((int64_t)N - 1) * sn + D) * 2) : whole;
+}
+#endif
 
 inline int dtype_size(int dt) { return dt == SFA_DTYPE_F32 ? 4 : 2; }
 

@@ -58,6 +58,8 @@ struct FwdArgs {
     int n_qtiles, hgroups;
     unsigned q_range, k_range, v_range, o_range;  // byte extent of one (b, head) slice
     int prio;              // tuning knob (SFA_FWD_PRIO): raised priority for waves 4..7
+    const int* cu;         // packed batches: device row offsets [B + 1] (else null), see Problem
+    int n_total;           // rows of the packed tensors
 };
 
 __device__ __forceinline__ float half_swap_max(float x) {
@@ -102,9 +104,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
     const int g = a.Hq / a.Hkv;
     const int hh = wave % a.hpw, rbi = wave / a.hpw;
     const int head = hk * g + hg * a.hpw + hh;
-    const int N = a.N, W = a.window, ns = a.num_sink;
+    const SeqInfo sq = seq_of(a.cu, b, a.N);
+    const int N = sq.N, ns = a.num_sink;
+    const int W = a.window < N ? a.window : N;
     const int BM = 32 * a.rb;
     const int q0 = qt * BM;
+    if (q0 >= N) return;   // packed batches: the grid is sized for the longest sequence
     const int q1 = (q0 + BM < N) ? q0 + BM : N;
     const int qw0 = q0 + 32 * rbi;
     const int qw_hi = (qw0 + 31 < N - 1) ? qw0 + 31 : N - 1;
@@ -123,14 +128,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
     const int nt = ts_hi + (tw_hi - tw_lo);
 
     // ---- buffer descriptors (wave-uniform)
-    const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
-    const char* kb = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
-    const char* vb = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
-    char* ob = a.o.ptr + ((int64_t)b * a.o.sb + (int64_t)head * a.o.sh) * 2;
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, a.k_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, a.v_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, a.o_range, 0x00020000);
+    const char* qb = a.q.ptr + ((int64_t)sq.bb * a.q.sb + (int64_t)head * a.q.sh + (int64_t)sq.row0 * a.q.sn) * 2;
+    const char* kb = a.k.ptr + ((int64_t)sq.bb * a.k.sb + (int64_t)hk * a.k.sh + (int64_t)sq.row0 * a.k.sn) * 2;
+    const char* vb = a.v.ptr + ((int64_t)sq.bb * a.v.sb + (int64_t)hk * a.v.sh + (int64_t)sq.row0 * a.v.sn) * 2;
+    char* ob = a.o.ptr + ((int64_t)sq.bb * a.o.sb + (int64_t)head * a.o.sh + (int64_t)sq.row0 * a.o.sn) * 2;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, seq_range(a.cu, a.q_range, N, a.q.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, seq_range(a.cu, a.k_range, N, a.k.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, seq_range(a.cu, a.v_range, N, a.v.sn, D), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, seq_range(a.cu, a.o_range, N, a.o.sn, D), 0x00020000);
 
     // ---- Q fragments: B operand of S^T = K Q^T; lane (r,h) holds Q[qrow][16ks + 8h .. +8)
     frag qf[DK];
@@ -320,7 +325,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), ro, off, 0, 0);
             }
         }
-    if (h == 0 && qrow < N) a.lse[((int64_t)b * a.Hq + head) * N + qrow] = (m + __log2f(lt)) * kLn2;
+    if (h == 0 && qrow < N) {
+        const int64_t lrow = a.cu ? (int64_t)head * a.n_total + sq.row0 : ((int64_t)b * a.Hq + head) * N;
+        a.lse[lrow + qrow] = (m + __log2f(lt)) * kLn2;
+    }
 }
 
 template <typename T, int D, int NW>
@@ -371,8 +379,13 @@ bool fwd_mfma_supported(int dtype, int D) {
 
 int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
              const float* s_aux, const Problem& p, hipStream_t stream) {
-    if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(o)))
+    if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(o))) {
+        if (p.cu) {
+            set_error("packed (varlen) forward needs 16-byte aligned rows and < 4 GiB head slices");
+            return SFA_ERR_UNSUPPORTED;
+        }
         return fwd_generic(q, k, v, o, lse, s_aux, p, stream);  // unaligned / >4 GiB slices: exact path
+    }
     int NW = 8;
     if (const char* e = getenv("SFA_FWD_NW")) {
         const int x = atoi(e);
@@ -383,6 +396,7 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.q = make_view(q); a.k = make_view(k); a.v = make_view(v); a.o = make_view(o);
     a.lse = lse; a.s_aux = s_aux;
     a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
+    a.cu = p.cu; a.n_total = p.n_total;
     a.num_sink = p.num_sink;
     a.window = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);
     a.scale_log2 = p.scale * kLog2e;

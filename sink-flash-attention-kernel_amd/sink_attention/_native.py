@@ -55,6 +55,12 @@ def _bind(lib):
     lib.sfa_bwd_workspace_bytes.argtypes = [i64, i64, i64, i64, i64, i32, i32, i32, u32]
     lib.sfa_bwd.restype = i32
     lib.sfa_bwd.argtypes = [P, P, P, P, P, vp, vp, P, P, P, vp, vp, sz, i32, i32, f32, u32, vp]
+    lib.sfa_varlen_supported.restype = i32
+    lib.sfa_varlen_supported.argtypes = [i32, i64]
+    lib.sfa_fwd_varlen.restype = i32
+    lib.sfa_fwd_varlen.argtypes = [P, P, P, P, vp, vp, vp, i32, i32, i32, i32, f32, u32, vp]
+    lib.sfa_bwd_varlen.restype = i32
+    lib.sfa_bwd_varlen.argtypes = [P, P, P, P, P, vp, vp, P, P, P, vp, vp, i32, i32, vp, sz, i32, i32, f32, u32, vp]
     lib.sfa_decode_workspace_bytes.restype = sz
     lib.sfa_decode_workspace_bytes.argtypes = [i64, i64, i64, i64, i64, i32]
     lib.sfa_decode.restype = i32

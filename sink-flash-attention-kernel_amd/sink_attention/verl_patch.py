@@ -86,15 +86,15 @@ def _sink_flash_attention_forward(
     if (ENABLE_VARLEN and (varlen or packed) and is_causal and attention_mask is None and softcap is None
             and query_states.shape[0] == 1 and query_states.shape[1] == key_states.shape[1]):
         from .varlen import seq_bounds_from_position_ids, sink_flash_attention_varlen
-        if varlen:
-            cu = cu_seq_lens_q.tolist()
+        if varlen:     # device offsets + the longest length: no host synchronisation
+            cu, max_len = cu_seq_lens_q, int(max_length_q)
         else:
-            cu = seq_bounds_from_position_ids(position_ids[0] if position_ids.dim() > 1 else position_ids)
+            cu, max_len = seq_bounds_from_position_ids(position_ids[0] if position_ids.dim() > 1 else position_ids), None
         T = query_states.shape[1]
         out = sink_flash_attention_varlen(query_states.transpose(1, 2), key_states.transpose(1, 2),
                                           value_states.transpose(1, 2), cu, num_sink=0,
                                           window_size=sliding_window if sliding_window is not None else T,
-                                          s_aux=_local_s_aux(s_aux, query_states.shape[2]))
+                                          s_aux=_local_s_aux(s_aux, query_states.shape[2]), max_seqlen=max_len)
         return out.transpose(1, 2).contiguous()
     if varlen or packed or not is_causal or attention_mask is not None or softcap is not None:
         if s_aux is not None:

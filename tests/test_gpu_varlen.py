@@ -45,6 +45,52 @@ def test_varlen_fwd_bwd_matches_per_sequence_oracle(dtype):
     assert maxdiff(sad.grad, dsa_r) < tg * 10
 
 
+@pytest.mark.parametrize("Hq,Hkv,D,ns,W,cu", [
+    (8, 2, 128, 4, 300, [0, 1000, 1001, 1900, 4000, 4127]),      # long + 1-row + ragged sequences, GQA
+    (4, 4, 64, 0, 64, [0, 63, 64, 200, 200, 455]),               # MHA, D=64, an EMPTY sequence in the pack
+    (8, 1, 80, 130, 50, [0, 129, 700]),                          # MQA, D=80, sinks longer than a key block
+    (4, 2, 96, 2, 100000, [0, 257, 640])])                       # window larger than every sequence
+def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu):
+    """The packed kernels (cu_seqlens inside the grid) against the per-sequence oracle, forward and backward, and
+    against the sequence-by-sequence path of the same library."""
+    from sink_attention import _native
+    from sink_attention.varlen import sink_flash_attention_varlen
+    from sink_attention.sink_flash_attention import _sink_flash_attention_ex
+    g = torch.Generator().manual_seed(33)
+    T = cu[-1]
+    dtype = torch.bfloat16
+    q, k, v = rand((1, Hq, T, D), g, dtype), rand((1, Hkv, T, D), g, dtype), rand((1, Hkv, T, D), g, dtype)
+    do = rand((1, Hq, T, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = sink_flash_attention_varlen(qd, kd, vd, cu, num_sink=ns, window_size=W, s_aux=sad)
+    assert _native.last_path().startswith("fwd_mfma")
+    out.backward(do.to(DEV))
+    assert "dkdvws8" in _native.last_path()
+    o_r, dq_r, dk_r, dv_r, dsa_r = _per_seq_oracle(q, k, v, do, cu, ns, W, sa)
+    assert maxdiff(out, o_r) < 2e-2
+    assert maxdiff(qd.grad, dq_r) < 1.5e-1 and maxdiff(kd.grad, dk_r) < 1.5e-1 and maxdiff(vd.grad, dv_r) < 1.5e-1
+    assert maxdiff(sad.grad, dsa_r) < 1.5
+    # same numbers as running each sequence alone through the ordinary op (same kernels, same tile walk)
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b > a:
+            alone = _sink_flash_attention_ex(qd.detach()[:, :, a:b], kd.detach()[:, :, a:b], vd.detach()[:, :, a:b],
+                                             ns, W, s_aux=sad.detach())
+            assert torch.equal(alone, out.detach()[:, :, a:b])
+
+
+def test_varlen_device_cu_seqlens_no_host_sync():
+    from sink_attention.varlen import sink_flash_attention_varlen
+    g = torch.Generator().manual_seed(34)
+    cu = [0, 100, 356]
+    q, k, v = (rand((1, 4, 356, 64), g, torch.float16).to(DEV) for _ in range(3))
+    ref = sink_flash_attention_varlen(q, k, v, cu, num_sink=2, window_size=32)
+    cud = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    out = sink_flash_attention_varlen(q, k, v, cud, num_sink=2, window_size=32, max_seqlen=300)   # upper bound is fine
+    assert torch.equal(out, ref)
+
+
 def test_boundary_routes_packed_batches_when_enabled():
     import sink_attention.verl_patch as vp
     g = torch.Generator().manual_seed(32)
