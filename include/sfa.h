@@ -163,6 +163,20 @@ int sfa_decode_ring(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_ten
                     const sfa_tensor* o, const float* s_aux, void* workspace, size_t workspace_bytes,
                     float scale, unsigned flags, void* stream);
 
+/*
+ * One generation step on the sink + ring cache in ONE pass: store the new token's K/V [B, Hkv, 1, D] into ring slot
+ * `write_pos` AND attend q over the cache as it is after that store.  Replaces SinkCacheLayer.update()'s slot write +
+ * torch.cat linearisation (sink_attention/cache.py:129-216) followed by sink_decode_attention.
+ *   window_len: valid ring slots AFTER the append (min(old + 1, window_size)); 0 <= write_pos < window_len.
+ *   The slot's previous content (the evicted token) is never read; the caller advances write_pos / window_len.
+ *   workspace: sfa_decode_workspace_bytes(B, Hq, Hkv, sink_len + window_len, D, dtype)
+ */
+int sfa_decode_ring_step(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v, int64_t sink_len,
+                         const sfa_tensor* window_k, const sfa_tensor* window_v, int64_t window_len,
+                         int64_t write_pos, const sfa_tensor* k_new, const sfa_tensor* v_new, const sfa_tensor* o,
+                         const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,7 +268,8 @@ namespace {
 // shared by sfa_decode (one contiguous key segment) and sfa_decode_ring (sink buffer + window ring)
 int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
                   const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
-                  size_t workspace_bytes, float scale, void* stream) {
+                  size_t workspace_bytes, float scale, void* stream, const sfa_tensor* k_new = nullptr,
+                  const sfa_tensor* v_new = nullptr, int64_t new_slot = -1) {
     g_err[0] = 0;
     int st;
     if ((st = check_tensor(q, "q")) || (st = check_tensor(k, "k")) || (st = check_tensor(v, "v")) ||
@@ -295,12 +296,23 @@ int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
                       (long long)k2->shape[2]);
     }
     SFA_CHECK_ARG(n1 + n2 < (1ll << 31) - 4096, "N_kv too large");
+    if (k_new || v_new) {       // fused cache step: the new token's K/V, stored into ring slot new_slot by the kernel
+        SFA_CHECK_ARG(k_new && v_new && k2 && v2, "fused step needs k_new, v_new and the window ring");
+        if ((st = check_tensor(k_new, "k_new")) || (st = check_tensor(v_new, "v_new")) ||
+            (st = same_shape(k_new, v_new, "k_new", "v_new")))
+            return st;
+        SFA_CHECK_ARG(k_new->dtype == k2->dtype && k_new->shape[0] == k2->shape[0] && k_new->shape[1] == k2->shape[1] &&
+                          k_new->shape[2] == 1 && k_new->shape[3] == k2->shape[3],
+                      "k_new / v_new must be [B, H_kv, 1, D] in the ring's dtype");
+        SFA_CHECK_ARG(new_slot >= 0 && new_slot < n2, "write slot %lld outside the %lld valid ring slots",
+                      (long long)new_slot, (long long)n2);
+    }
     if (q->shape[0] == 0 || q->shape[1] == 0) return SFA_OK;
     DecodePlan pl;
     st = decode_plan(q->shape[0], q->shape[1], k->shape[1], n1 + n2, q->shape[3], q->dtype, &pl);
     if (st) return st;
     const int es = dtype_size(q->dtype);
-    const sfa_tensor* ts[5] = {q, k, v, k2, v2};
+    const sfa_tensor* ts[7] = {q, k, v, k2, v2, k_new, v_new};
     for (const sfa_tensor* t : ts) {
         if (!t || t->shape[2] == 0) continue;
         SFA_CHECK_ARG(((uintptr_t)t->ptr % 16) == 0 && (t->stride[0] * es) % 16 == 0 && (t->stride[1] * es) % 16 == 0 &&
@@ -314,7 +326,7 @@ int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
         return SFA_ERR_WORKSPACE;
     }
     return decode_launch(q, k, v, n1, n2 ? k2 : nullptr, n2 ? v2 : nullptr, n2, o, s_aux, workspace, scale, pl,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, k_new, v_new, (int)new_slot);
 }
 
 }  // namespace
@@ -336,6 +348,18 @@ int sfa_decode_ring(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_ten
     (void)flags;
     return decode_common(q, sink_k, sink_v, sink_len, window_k, window_v, window_len, o, s_aux, workspace,
                          workspace_bytes, scale, stream);
+}
+
+int sfa_decode_ring_step(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v, int64_t sink_len,
+                         const sfa_tensor* window_k, const sfa_tensor* window_v, int64_t window_len,
+                         int64_t write_pos, const sfa_tensor* k_new, const sfa_tensor* v_new, const sfa_tensor* o,
+                         const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
+                         void* stream) {
+    (void)flags;
+    g_err[0] = 0;
+    SFA_CHECK_ARG(k_new != nullptr && v_new != nullptr, "k_new / v_new: null tensor descriptor");
+    return decode_common(q, sink_k, sink_v, sink_len, window_k, window_v, window_len, o, s_aux, workspace,
+                         workspace_bytes, scale, stream, k_new, v_new, write_pos);
 }
 
 }  // extern "C"

@@ -56,8 +56,16 @@ __device__ __forceinline__ void cvt16B(const u32x4& raw, float (&f)[EPL]) {
 // Keys come from up to two segments (k, v: rows [0, N1); k2, v2: rows [N1, Nkv)): a contiguous cache has N1 = Nkv;
 // the sink + ring cache passes the sink buffer and the window ring (softmax is order-invariant, so the ring is read
 // in place, no linearisation copy).
+// Fused cache step (sfa_decode_ring_step): `fr.slot` >= 0 names the ring slot the token being decoded goes to.  That
+// slot's OLD content (the evicted token, or nothing yet) is never read: the key at that position comes from fr.kn /
+// fr.vn, and the first split's first lanes store it into the ring, so append + attention are one launch.
+struct Fresh {
+    View kn, vn;
+    int slot;
+};
+
 template <typename T, int LPK, int GT>
-__global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View v, View k2, View v2, int N1,
+__global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View v, View k2, View v2, int N1, Fresh fr,
                                                           float* __restrict__ Mp, float* __restrict__ Lp,
                                                           float* __restrict__ Op, int Hq, int Hkv, int Nkv, int D,
                                                           int kps, int S, float scale) {
@@ -85,6 +93,16 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
     const T* vb = reinterpret_cast<const T*>(v.ptr) + (int64_t)b * v.sb + (int64_t)hk * v.sh + d0;
     const T* kb2 = reinterpret_cast<const T*>(k2.ptr) + (int64_t)b * k2.sb + (int64_t)hk * k2.sh + d0;
     const T* vb2 = reinterpret_cast<const T*>(v2.ptr) + (int64_t)b * v2.sb + (int64_t)hk * v2.sh + d0;
+    const T* knb = kb2;
+    const T* vnb = vb2;
+    if (fr.slot >= 0) {
+        knb = reinterpret_cast<const T*>(fr.kn.ptr) + (int64_t)b * fr.kn.sb + (int64_t)hk * fr.kn.sh + d0;
+        vnb = reinterpret_cast<const T*>(fr.vn.ptr) + (int64_t)b * fr.vn.sb + (int64_t)hk * fr.vn.sh + d0;
+        if (split == 0 && wave == 0 && kg == 0 && dact) {      // the append: one 16-byte piece per lane
+            *reinterpret_cast<u32x4*>(const_cast<T*>(kb2) + (int64_t)fr.slot * k2.sn) = *reinterpret_cast<const u32x4*>(knb);
+            *reinterpret_cast<u32x4*>(const_cast<T*>(vb2) + (int64_t)fr.slot * v2.sn) = *reinterpret_cast<const u32x4*>(vnb);
+        }
+    }
 
     for (int h0 = 0; h0 < g; h0 += GT) {
         float qf[GT][EPL];
@@ -114,8 +132,9 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
                 valid[u] = kk < k_end;
                 const int kc = valid[u] ? kk : (k_end - 1);
                 const bool seg1 = kc < N1;
-                const T* kp = seg1 ? kb + (int64_t)kc * k.sn : kb2 + (int64_t)(kc - N1) * k2.sn;
-                const T* vp = seg1 ? vb + (int64_t)kc * v.sn : vb2 + (int64_t)(kc - N1) * v2.sn;
+                const bool fresh = kc - N1 == fr.slot;       // fr.slot < 0: never
+                const T* kp = seg1 ? kb + (int64_t)kc * k.sn : (fresh ? knb : kb2 + (int64_t)(kc - N1) * k2.sn);
+                const T* vp = seg1 ? vb + (int64_t)kc * v.sn : (fresh ? vnb : vb2 + (int64_t)(kc - N1) * v2.sn);
                 kraw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp));
                 vraw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vp));
             }
@@ -251,17 +270,17 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
 }
 
 template <typename T, int LPK>
-int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, View k2, View v2, int N1, float* Mp,
+int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, View k2, View v2, int N1, Fresh fr, float* Mp,
                  float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, int kps, int S, float scale) {
     switch (gt) {
         case 8:
-            decode_split_kernel<T, LPK, 8><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            decode_split_kernel<T, LPK, 8><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
             break;
         case 4:
-            decode_split_kernel<T, LPK, 4><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            decode_split_kernel<T, LPK, 4><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
             break;
         default:
-            decode_split_kernel<T, LPK, 1><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            decode_split_kernel<T, LPK, 1><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
             break;
     }
     return launch_status("decode_split");
@@ -269,10 +288,10 @@ int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, 
 
 template <typename T>
 int launch_split_lpk(const DecodePlan& pl, dim3 grid, hipStream_t stream, View q, View k, View v, View k2, View v2,
-                     int N1, float* Mp, float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, float scale) {
+                     int N1, Fresh fr, float* Mp, float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, float scale) {
 #define SFA_LPK_CASE(L)                                                                                        \
     case L:                                                                                                    \
-        return launch_split<T, L>(pl.gt, grid, stream, q, k, v, k2, v2, N1, Mp, Lp, Op, Hq, Hkv, Nkv, D,       \
+        return launch_split<T, L>(pl.gt, grid, stream, q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D,   \
                                   pl.keys_per_split, pl.splits, scale);
     switch (pl.lpk) {
         SFA_LPK_CASE(2)
@@ -327,11 +346,14 @@ int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int 
 
 int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
                   const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
-                  float scale, const DecodePlan& pl, hipStream_t stream) {
+                  float scale, const DecodePlan& pl, hipStream_t stream, const sfa_tensor* k_new,
+                  const sfa_tensor* v_new, int new_slot) {
     const int B = (int)q->shape[0], Hq = (int)q->shape[1], D = (int)q->shape[3];
     const int Hkv = (int)k->shape[1], Nkv = (int)(n1 + n2), N1 = (int)n1;
     const View kv2 = k2 ? make_view(k2) : make_view(k);
     const View vv2 = v2 ? make_view(v2) : make_view(v);
+    Fresh fr{kv2, vv2, -1};
+    if (k_new && v_new && new_slot >= 0) fr = Fresh{make_view(k_new), make_view(v_new), new_slot};
     const int S = pl.splits;
     float* Mp = reinterpret_cast<float*>(workspace);
     float* Lp = Mp + (int64_t)B * Hq * S;
@@ -339,13 +361,13 @@ int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
     dim3 grid(S, Hkv, B);
     int st;
     if (q->dtype == SFA_DTYPE_F32)
-        st = launch_split_lpk<float>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, Mp, Lp,
+        st = launch_split_lpk<float>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, Mp, Lp,
                                      Op, Hq, Hkv, Nkv, D, scale);
     else if (q->dtype == SFA_DTYPE_F16)
-        st = launch_split_lpk<f16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, Mp, Lp,
+        st = launch_split_lpk<f16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, Mp, Lp,
                                      Op, Hq, Hkv, Nkv, D, scale);
     else
-        st = launch_split_lpk<bf16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, Mp, Lp,
+        st = launch_split_lpk<bf16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, Mp, Lp,
                                       Op, Hq, Hkv, Nkv, D, scale);
     if (st != SFA_OK) return st;
     dim3 rgrid(Hq, B);
@@ -355,7 +377,7 @@ int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
         decode_reduce_kernel<f16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
     else
         decode_reduce_kernel<bf16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
-    set_path("decode_splitkv%s_lpk%d_gt%d_s%d", k2 ? "_ring" : "", pl.lpk, pl.gt, S);
+    set_path("decode_splitkv%s_lpk%d_gt%d_s%d", fr.slot >= 0 ? "_ringstep" : (k2 ? "_ring" : ""), pl.lpk, pl.gt, S);
     return launch_status("decode_reduce");
 }
 

@@ -67,6 +67,8 @@ def _bind(lib):
     lib.sfa_decode.argtypes = [P, P, P, P, vp, vp, sz, f32, u32, vp]
     lib.sfa_decode_ring.restype = i32
     lib.sfa_decode_ring.argtypes = [P, P, P, i64, P, P, i64, P, vp, vp, sz, f32, u32, vp]
+    lib.sfa_decode_ring_step.restype = i32
+    lib.sfa_decode_ring_step.argtypes = [P, P, P, i64, P, P, i64, i64, P, P, P, vp, vp, sz, f32, u32, vp]
 
 
 def lib():

@@ -117,6 +117,60 @@ class SinkCacheLayer(_HFLayer if _HAS_HF else object):
         return sink_decode_attention_ring(q, self.sink_k, self.sink_v, self.sink_len, self.window_k, self.window_v,
                                           self.window_len, s_aux=s_aux)
 
+    def decode_step(self, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor,
+                    s_aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One generation step = ``append(k_new, v_new)`` + ``decode_attention(q)``, as ONE kernel pass once the cache
+        is in steady state (``sfa_decode_ring_step``: the kernel stores the token into its ring slot and attends over
+        the updated cache; no ``torch.cat``, no separate slot-write launches)."""
+        steady = (self.prefilled and self.window_size > 0 and k_new.shape[2] == 1 and self.window_k is not None
+                  and self.window_k.is_cuda)
+        if not steady:
+            self.append(k_new, v_new)
+            return self.decode_attention(q, s_aux=s_aux)
+        pos = self.write_pos
+        new_len = min(self.window_len + 1, self.window_size)
+        out = self._ring_step(q, k_new, v_new, new_len, pos, s_aux)
+        self.seen_tokens += 1
+        self.write_pos = (pos + 1) % self.window_size
+        self.window_len = new_len
+        return out
+
+    def _ring_step(self, q, k_new, v_new, new_len, pos, s_aux):
+        """sfa_decode_ring_step with the per-layer constants (buffer descriptors, workspace) built once: at B=1 the
+        step is host-bound, so the Python work per token is kept to the four per-call descriptors."""
+        import math
+        from . import _native as N
+        st = getattr(self, "_step_state", None)
+        key = (self.sink_k.data_ptr(), self.window_k.data_ptr(), q.shape, q.dtype)
+        if st is None or st["key"] != key:
+            B, H_q, _one, D = q.shape
+            H_kv = self.sink_k.shape[1]
+            if q.dtype != self.window_k.dtype or q.dtype not in N.SFA_DTYPE:
+                raise TypeError("q and the cache buffers must share one dtype")
+            assert _one == 1 and H_q % H_kv == 0 and (D * q.element_size()) % 16 == 0
+            lib = N.lib()
+            ws_bytes = lib.sfa_decode_workspace_bytes(B, H_q, H_kv, self.num_sink + self.window_size, D,
+                                                      N.SFA_DTYPE[q.dtype])
+            st = dict(key=key, lib=lib, scale=1.0 / math.sqrt(D),
+                      descs=[N.desc(t) for t in (self.sink_k, self.sink_v, self.window_k, self.window_v)],
+                      ws=torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8))
+            self._step_state = st
+        N.require_gpu(q, k_new, v_new, s_aux)
+        if k_new.dtype != q.dtype or v_new.dtype != q.dtype or k_new.shape != v_new.shape:
+            raise TypeError("k_new / v_new must be [B, H_kv, 1, D] tensors of q's dtype")
+        q, k_new, v_new = N.unit_inner(q.detach()), N.unit_inner(k_new.detach()), N.unit_inner(v_new.detach())
+        s_aux_f = s_aux.detach().contiguous().float() if s_aux is not None else None
+        out = torch.empty(q.shape, device=q.device, dtype=q.dtype)
+        sk, sv, wk, wv = st["descs"]
+        with torch.cuda.device(q.device):
+            rc = st["lib"].sfa_decode_ring_step(N.desc(q), sk, sv, self.sink_len, wk, wv, new_len, pos, N.desc(k_new),
+                                                N.desc(v_new), N.desc(out),
+                                                s_aux_f.data_ptr() if s_aux_f is not None else None,
+                                                st["ws"].data_ptr(), st["ws"].numel(), st["scale"], 0,
+                                                N.stream_ptr(q.device))
+        N.check(rc, "sfa_decode_ring_step")
+        return out
+
     # ------------------------------------------------------- HF layer surface
     def get_seq_length(self, *_, **__) -> int:
         return self.sink_len + self.window_len
@@ -175,6 +229,13 @@ class SinkAttentionCache(_HFCache if _HAS_HF else object):
         self._layer(layer_idx).append(key_states, value_states)
         if layer_idx == 0:
             self._seen_tokens = self.layers[0].seen_tokens
+
+    def decode_step(self, q, key_states, value_states, layer_idx: int, s_aux=None):
+        """Fused cache update + attention of one layer for one new token (``SinkCacheLayer.decode_step``)."""
+        out = self._layer(layer_idx).decode_step(q, key_states, value_states, s_aux=s_aux)
+        if layer_idx == 0:
+            self._seen_tokens = self.layers[0].seen_tokens
+        return out
 
     def get_seq_length(self, layer_idx: int = 0, *_, **__) -> int:
         return self.layers[layer_idx].get_seq_length() if layer_idx < len(self.layers) else 0

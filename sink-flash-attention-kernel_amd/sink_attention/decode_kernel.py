@@ -56,7 +56,8 @@ def sink_decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
 
 def sink_decode_attention_ring(q: torch.Tensor, sink_k: torch.Tensor, sink_v: torch.Tensor, sink_len: int,
                                window_k: torch.Tensor, window_v: torch.Tensor, window_len: int,
-                               s_aux: torch.Tensor = None) -> torch.Tensor:
+                               s_aux: torch.Tensor = None, k_new: torch.Tensor = None, v_new: torch.Tensor = None,
+                               write_pos: int = -1) -> torch.Tensor:
     """Decode over a sink buffer + window ring WITHOUT linearising them (``sfa_decode_ring``).
 
     Equivalent to ``sink_decode_attention(q, cat(sink_k[:, :, :sink_len], ring in any order), ...)`` - softmax does
@@ -64,6 +65,11 @@ def sink_decode_attention_ring(q: torch.Tensor, sink_k: torch.Tensor, sink_v: to
     reference's ``SinkCacheLayer.get_kv`` (cache.py:185-216).
         q [B,H_q,1,D]; sink_k/v [B,H_kv,num_sink,D] (first ``sink_len`` rows valid);
         window_k/v [B,H_kv,window_size,D] (first ``window_len`` slots valid; all of them once the ring is full).
+
+    With ``k_new`` / ``v_new`` [B,H_kv,1,D] and ``write_pos`` the call is a whole generation step
+    (``sfa_decode_ring_step``): the kernel stores the new token into ring slot ``write_pos`` (``window_k`` /
+    ``window_v`` are modified IN PLACE) and attends over the cache as it is after that store; ``window_len`` is then the
+    number of valid slots AFTER the append.
     """
     N.require_gpu(q, sink_k, sink_v, window_k, window_v, s_aux)
     B, H_q, N_q, D = q.shape
@@ -88,7 +94,20 @@ def sink_decode_attention_ring(q: torch.Tensor, sink_k: torch.Tensor, sink_v: to
             t = t.contiguous()
         return t
 
-    q, sink_k, sink_v, window_k, window_v = (rows16(t) for t in (q, sink_k, sink_v, window_k, window_v))
+    fused = k_new is not None
+    if fused:
+        assert v_new is not None and k_new.shape == (B, H_kv, 1, D) and v_new.shape == k_new.shape
+        assert 0 <= write_pos < window_len, f"write_pos {write_pos} outside the {window_len} valid slots"
+        for t in (window_k, window_v):   # the kernel writes the ring in place: no silent copies allowed here
+            es = t.element_size()
+            assert t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all((t.stride(i) * es) % 16 == 0 for i in range(3)), \
+                "fused cache step: the ring buffers must have 16-byte aligned rows"
+        if k_new.dtype != q.dtype or v_new.dtype != q.dtype:
+            raise TypeError("k_new / v_new must have q's dtype")
+        k_new, v_new = rows16(k_new), rows16(v_new)
+    q, sink_k, sink_v = (rows16(t) for t in (q, sink_k, sink_v))
+    if not fused:
+        window_k, window_v = rows16(window_k), rows16(window_v)
     s_aux_f = None
     if s_aux is not None:
         assert s_aux.shape == (H_q,), f"s_aux shape must be [H_q={H_q}], got {s_aux.shape}"
@@ -98,9 +117,16 @@ def sink_decode_attention_ring(q: torch.Tensor, sink_k: torch.Tensor, sink_v: to
     ws_bytes = lib.sfa_decode_workspace_bytes(B, H_q, H_kv, int(sink_len) + int(window_len), D, N.SFA_DTYPE[q.dtype])
     ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)
     with torch.cuda.device(q.device):
-        st = lib.sfa_decode_ring(N.desc(q), N.desc(sink_k), N.desc(sink_v), int(sink_len), N.desc(window_k),
-                                 N.desc(window_v), int(window_len), N.desc(out),
-                                 s_aux_f.data_ptr() if s_aux_f is not None else None, ws.data_ptr(), ws.numel(),
-                                 1.0 / math.sqrt(D), 0, N.stream_ptr(q.device))
-    N.check(st, "sfa_decode_ring")
+        if fused:
+            st = lib.sfa_decode_ring_step(N.desc(q), N.desc(sink_k), N.desc(sink_v), int(sink_len), N.desc(window_k),
+                                          N.desc(window_v), int(window_len), int(write_pos), N.desc(k_new),
+                                          N.desc(v_new), N.desc(out),
+                                          s_aux_f.data_ptr() if s_aux_f is not None else None, ws.data_ptr(),
+                                          ws.numel(), 1.0 / math.sqrt(D), 0, N.stream_ptr(q.device))
+        else:
+            st = lib.sfa_decode_ring(N.desc(q), N.desc(sink_k), N.desc(sink_v), int(sink_len), N.desc(window_k),
+                                     N.desc(window_v), int(window_len), N.desc(out),
+                                     s_aux_f.data_ptr() if s_aux_f is not None else None, ws.data_ptr(), ws.numel(),
+                                     1.0 / math.sqrt(D), 0, N.stream_ptr(q.device))
+    N.check(st, "sfa_decode_ring_step" if fused else "sfa_decode_ring")
     return out

@@ -198,3 +198,37 @@ def test_ring_decode_c5_policy_shape():
     keep = torch.tensor(list(range(ns)) + list(range(ns + 7, ns + W + 7)))
     ref = O.decode_dense(q[:4], k[:4][:, :, keep], v[:4][:, :, keep])
     assert_close(out[:4], ref.bfloat16(), 1e-2, 1e-2, "C5 policy")
+
+
+@pytest.mark.parametrize("dtype,Hq,Hkv,D,ns,W,prefill", [
+    (torch.float16, 32, 8, 128, 4, 64, 30),      # ring not full yet, then fills and wraps
+    (torch.bfloat16, 8, 8, 64, 2, 16, 100),      # full ring from the start (prefill longer than the window)
+    (torch.float32, 4, 1, 80, 0, 8, 3),          # no sinks, MQA, fp32, D=80
+    (torch.float16, 8, 2, 128, 4, 32, 2)])       # prefill shorter than num_sink (sink buffer partly filled)
+def test_fused_cache_step_matches_append_then_decode(dtype, Hq, Hkv, D, ns, W, prefill):
+    """decode_step (sfa_decode_ring_step: slot store + attention in one pass) against append() + decode_attention()
+    on a twin cache, and against the oracle on the chronological keys, across wrap-around."""
+    from sink_attention import _native
+    from sink_attention.cache import SinkCacheLayer
+    g = torch.Generator().manual_seed(91)
+    B = 2
+    a, b = SinkCacheLayer(ns, W), SinkCacheLayer(ns, W)
+    kp, vp = rand((B, Hkv, prefill, D), g, dtype).to(DEV), rand((B, Hkv, prefill, D), g, dtype).to(DEV)
+    a.update(kp, vp)
+    b.update(kp, vp)
+    sa = rand((Hq,), g, torch.float32, 0.5).to(DEV)
+    fused_seen = False
+    for step in range(W + 5):
+        q = rand((B, Hq, 1, D), g, dtype).to(DEV)
+        kn, vn = rand((B, Hkv, 1, D), g, dtype).to(DEV), rand((B, Hkv, 1, D), g, dtype).to(DEV)
+        out = a.decode_step(q, kn, vn, s_aux=sa)
+        fused_seen |= "ringstep" in _native.last_path()
+        b.append(kn, vn)
+        ref = b.decode_attention(q, s_aux=sa)
+        assert torch.equal(out, ref), step
+        assert (a.write_pos, a.window_len, a.sink_len, a.seen_tokens) == (b.write_pos, b.window_len, b.sink_len, b.seen_tokens)
+        assert torch.equal(a.window_k, b.window_k) and torch.equal(a.window_v, b.window_v)
+    assert fused_seen
+    kc, vc = a.get_kv()
+    o_ref = O.decode_dense(q.cpu(), kc.cpu(), vc.cpu(), sa.cpu())
+    assert maxdiff(out, o_ref) < (1e-4 if dtype == torch.float32 else 1e-2)
