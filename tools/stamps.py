@@ -30,13 +30,6 @@ lib.sfa_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 rc = lib.sfa_debug_read_stamps(buf)
 names = ["dma issue", "lds reads landed", "S chain + exp (score)", "dP chain+pack (score) / MFMAs (acc)", "lds write (score)", "waitcnt+barrier", "(n_it)", "loop-top gap"]
 print("rc", rc, _native.last_path())
-which = sys.argv[1] if len(sys.argv) > 1 else "dkdv"
-if which == "fwd":
-    lib.sfa_debug_read_fwd_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-    rc = lib.sfa_debug_read_fwd_stamps(buf)
-    names = ["issue K/V loads", "QK^T (reads + 16 MFMA)", "softmax VALU", "PV (tr reads + 16 MFMA)", "ds_write next tile",
-             "barrier", "(n tiles)", "loop-top gap"]
-    print("forward kernel stamps, rc", rc)
 for w in range(8):
     vals = [buf[w * 8 + i] for i in range(8)]
     n_it = vals[6]
