@@ -89,6 +89,10 @@ int sfa_debug_set_stage_events(void* const* events, int count);
 /*
  * Forward.  valid(i,j) = (j <= i) && (j < num_sink || j >= i - window + 1)
  *   q,o  [B, Hq, N, D]     k,v [B, Hkv, N, D]   Hq % Hkv == 0
+ *        k,v may hold MORE rows than q (N_kv >= N): the queries are then the LAST N positions of the key sequence,
+ *        row i sits at position i + N_kv - N (chunked prefill, a sequence-parallel rank with its halo keys
+ *        prepended; the reference asserts N_q == N_kv).  MFMA kernels only: SFA_ERR_UNSUPPORTED for fp32 / other
+ *        head dims.  dk, dv of sfa_bwd are [B, Hkv, N_kv, D]; lse, dq follow q.
  *   lse  [B, Hq, N] float32, contiguous: log-sum-exp of the scaled scores of the row
  *        INCLUDING the s_aux logit (-inf for a row that sees nothing)
  *   s_aux  nullable, [Hq] float32: per-head extra logit that only enters the denominator

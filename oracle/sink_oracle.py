@@ -81,6 +81,10 @@ def sink_attention_dense(
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Dense masked softmax attention.  Returns (O [B,Hq,N,D], LSE [B,Hq,N]).
 
+    k / v may hold MORE rows than q (N_kv >= N_q): the queries are then the LAST N_q positions of the key sequence
+    (row i sits at position i + N_kv - N_q), the convention of chunked prefill / a sequence-parallel rank that got
+    its halo keys prepended.  Not a reference feature (it asserts N_q == N_kv, sink_flash_attention.py:494-498).
+
     Mask by -inf (tests/test_sink_attention.py:43); a row with no valid key and
     no s_aux gives O = 0 (``nan_to_num`` at :45, kernel: l==0 -> 1 at
     sink_flash_attention.py:183) and LSE = -inf.  ``s_aux`` is an extra logit
@@ -91,9 +95,9 @@ def sink_attention_dense(
     g = Hq // Hkv
     scale = 1.0 / math.sqrt(D)
     qf, kf, vf = q.to(dtype), _expand_kv(k.to(dtype), g), _expand_kv(v.to(dtype), g)
-    s = torch.matmul(qf, kf.transpose(-2, -1)) * scale                  # [B,Hq,N,N]
-    pos = torch.arange(N)
-    m = valid_mask(pos, pos, num_sink, window)
+    s = torch.matmul(qf, kf.transpose(-2, -1)) * scale                  # [B,Hq,N,Nk]
+    Nk = k.shape[2]
+    m = valid_mask(torch.arange(N) + (Nk - N), torch.arange(Nk), num_sink, window)
     s = s.masked_fill(~m, NEG_INF)
     if s_aux is not None:
         col = s_aux.to(dtype).view(1, Hq, 1, 1).expand(B, Hq, N, 1)
@@ -126,8 +130,8 @@ def sink_attention_bwd_dense(
     qf, kf, vf = q.to(dtype), _expand_kv(k.to(dtype), g), _expand_kv(v.to(dtype), g)
     dof = do.to(dtype)
     s = torch.matmul(qf, kf.transpose(-2, -1)) * scale
-    pos = torch.arange(N)
-    m = valid_mask(pos, pos, num_sink, window)
+    Nk = k.shape[2]
+    m = valid_mask(torch.arange(N) + (Nk - N), torch.arange(Nk), num_sink, window)
     p = torch.exp(s.masked_fill(~m, NEG_INF) - lse.unsqueeze(-1))
     p = torch.nan_to_num(p, nan=0.0)
     delta = (dof * o).sum(-1)                                           # [B,Hq,N]
@@ -137,8 +141,8 @@ def sink_attention_bwd_dense(
     dq = torch.matmul(ds, kf) * scale
     dk = torch.matmul(ds.transpose(-2, -1), qf) * scale
     if g > 1:
-        dk = dk.view(B, Hkv, g, N, D).sum(2)
-        dv = dv.view(B, Hkv, g, N, D).sum(2)
+        dk = dk.view(B, Hkv, g, Nk, D).sum(2)
+        dv = dv.view(B, Hkv, g, Nk, D).sum(2)
     ds_aux = None
     if s_aux is not None:
         sink_prob = torch.exp(s_aux.to(dtype).view(1, Hq, 1) - lse)

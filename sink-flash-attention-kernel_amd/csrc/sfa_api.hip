@@ -64,7 +64,9 @@ int check_prefill(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
     SFA_CHECK_ARG(q->dtype == k->dtype, "q and k differ in dtype");
     SFA_CHECK_ARG(q->shape[0] == k->shape[0], "batch mismatch: q %lld vs k %lld", (long long)q->shape[0],
                   (long long)k->shape[0]);
-    SFA_CHECK_ARG(q->shape[2] == k->shape[2], "prefill needs N_q == N_kv (q %lld, k %lld)", (long long)q->shape[2],
+    // the reference needs N_q == N_kv; here the keys may outnumber the queries (the queries are then the LAST N_q
+    // positions: chunked prefill, a sequence-parallel rank with its halo keys prepended)
+    SFA_CHECK_ARG(q->shape[2] <= k->shape[2], "prefill needs N_q <= N_kv (q %lld, k %lld)", (long long)q->shape[2],
                   (long long)k->shape[2]);
     SFA_CHECK_ARG(q->shape[3] == k->shape[3], "head dim mismatch");
     SFA_CHECK_ARG(k->shape[1] > 0 && q->shape[1] % k->shape[1] == 0, "H_q (%lld) must be divisible by H_kv (%lld)",
@@ -76,6 +78,7 @@ int check_prefill(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
     p->Hq = (int)q->shape[1];
     p->Hkv = (int)k->shape[1];
     p->N = (int)q->shape[2];
+    p->Nk = (int)k->shape[2];
     p->D = (int)q->shape[3];
     p->num_sink = num_sink;
     p->window = window;
@@ -131,6 +134,10 @@ int sfa_fwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     hipStream_t s = (hipStream_t)stream;
     if (!(flags & SFA_FLAG_FORCE_GENERIC) && fwd_mfma_supported(q->dtype, p.D))
         return fwd_mfma(q, k, v, o, lse, s_aux, p, s);
+    if (p.Nk != p.N) {
+        set_error("N_q != N_kv is served by the MFMA kernels only (16-bit dtypes, head dims 64/80/96/128)");
+        return SFA_ERR_UNSUPPORTED;
+    }
     return fwd_generic(q, k, v, o, lse, s_aux, p, s);
 }
 
@@ -174,7 +181,10 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     if (st) return st;
     if (use_mfma)
         st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, flags, s);
-    else
+    else if (p.Nk != p.N) {
+        set_error("N_q != N_kv is served by the MFMA kernels only (16-bit dtypes, head dims 64/80/96/128)");
+        st = SFA_ERR_UNSUPPORTED;
+    } else
         st = bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, s);
     record_stage(3, s);
     return st;
@@ -191,6 +201,7 @@ static int check_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tens
     int st = check_prefill(q, k, v, p, num_sink, window, scale);
     if (st) return st;
     SFA_CHECK_ARG(p->B == 1, "packed layout: batch dim must be 1 (got %d)", p->B);
+    SFA_CHECK_ARG(p->N == p->Nk, "packed layout: q and k must have the same number of rows");
     SFA_CHECK_ARG(cu != nullptr && n_seq >= 1, "cu_seqlens: need a device array of n_seq + 1 >= 2 offsets");
     SFA_CHECK_ARG(max_seqlen >= 1 && max_seqlen <= p->N, "max_seqlen %d out of range (total rows %d)", max_seqlen, p->N);
     if (!sfa_varlen_supported(q->dtype, p->D)) {
@@ -202,6 +213,7 @@ static int check_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tens
     run->N = max_seqlen;
     run->cu = cu;
     run->n_total = p->N;
+    run->Nk = 0;
     return SFA_OK;
 }
 

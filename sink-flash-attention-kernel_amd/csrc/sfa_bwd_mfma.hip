@@ -88,6 +88,7 @@ struct BwdArgs {
     const int* ds_prefix;            // [n_kblocks + 1] exclusive prefix of slices per key block
     const int* cu;                   // packed batches: device row offsets [B + 1] (else null), see Problem
     int n_total;                     // rows of the packed tensors
+    int Nk;                          // key rows (>= N): query row i sits at position i + Nk - N
     int ds_nt;                       // tuning knob (SFA_DS_NT): non-temporal hint on the dS stream loads of the dQ GEMM
     int64_t ds_chunks;               // chunks per head = ds_prefix[n_kblocks]
 };
@@ -976,24 +977,28 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     const bool acc_role = wave >= 4;
     const int r = lane & 31, h = lane >> 5;
     const SeqInfo sq = seq_of(a.cu, b, a.N);
-    const int N = sq.N, ns = a.num_sink;
-    const int W = a.window < N ? a.window : N;
+    const int N = sq.N, ns = a.num_sink;       // N = query rows
+    const int P = a.cu ? 0 : a.Nk - a.N;       // position of query row 0 among the keys
+    const int Nk = N + P;                      // key rows
+    const int W = a.window < Nk ? a.window : Nk;
     const int NT_ = a.cu ? a.n_total : N;      // rows of one head in the [B, Hq, 2, rows] row-constant buffer
     const int g = a.Hq / a.Hkv;
     const int kb0 = kb * kKB;
-    if (kb0 >= N) return;                      // packed batches: the grid is sized for the longest sequence
-    const int kb1 = (kb0 + kKB < N) ? kb0 + kKB : N;
+    if (kb0 >= Nk) return;                     // packed batches: the grid is sized for the longest sequence
+    const int kb1 = (kb0 + kKB < Nk) ? kb0 + kKB : Nk;
     const int kw0 = kb0 + 32 * kg;
     const int key = kw0 + r;
 
+    // rows that can see the block: key j is visible to row i iff j <= i + P and (j < ns or j >= i + P - W + 1)
     int i_hi;
     if (kb0 < ns) {
         i_hi = N;
     } else {
-        i_hi = kb1 - 1 + W;
+        i_hi = kb1 - 1 + W - P;
         if (i_hi > N) i_hi = N;
+        if (i_hi < 0) i_hi = 0;
     }
-    const int qt_lo = kb0 / QT;
+    const int qt_lo = (kb0 > P ? kb0 - P : 0) / QT;
     int qt_hi = (i_hi + QT - 1) / QT;
     if (qt_hi < qt_lo) qt_hi = qt_lo;
     const int nq = qt_hi - qt_lo;          // == dkdv_slices(kb, N, ns, W)
@@ -1086,8 +1091,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
         if (a.prio) __builtin_amdgcn_s_setprio(2);
         const char* kbase = a.k.ptr + ((int64_t)sq.bb * a.k.sb + (int64_t)hk * a.k.sh + (int64_t)sq.row0 * a.k.sn) * 2;
         const char* vbase = a.v.ptr + ((int64_t)sq.bb * a.v.sb + (int64_t)hk * a.v.sh + (int64_t)sq.row0 * a.v.sn) * 2;
-        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, seq_range(a.cu, a.k_range, N, a.k.sn, D), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, seq_range(a.cu, a.v_range, N, a.v.sn, D), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, seq_range(a.cu, a.k_range, Nk, a.k.sn, D), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, seq_range(a.cu, a.v_range, Nk, a.v.sn, D), 0x00020000);
         frag kf[DK], vf[DK];
 #pragma unroll
         for (int ks = 0; ks < DK; ++ks) {
@@ -1161,7 +1166,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
                     float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, l4[g4][e]));
                     if constexpr (!FULL) {
                         const int qi = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool valid = (key <= qi) && (key < ns || key + W > qi) && (qi < N);
+                        const bool valid = (key <= qi + P) && (key < ns || key + W > qi + P) && (qi < N);
                         p = valid ? p : 0.f;
                     }
                     pf[i] = p;
@@ -1196,7 +1201,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
             STAMP(7)
             STAMP(0)
             if (t < n_it) {
-                const bool full = (kw0 + 31 <= q0) && (q0 + 31 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 31));
+                const bool full = (kw0 + 31 <= q0 + P) && (q0 + 31 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 31 + P));
                 if (full)
                     score(std::true_type{}, ktag, std::integral_constant<int, (K + 1) % NST>{}, t & 1);
                 else
@@ -1348,8 +1353,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
 
         char* dkb = a.dk.ptr + ((int64_t)sq.bb * a.dk.sb + (int64_t)hk * a.dk.sh + (int64_t)sq.row0 * a.dk.sn) * 2;
         char* dvb = a.dv.ptr + ((int64_t)sq.bb * a.dv.sb + (int64_t)hk * a.dv.sh + (int64_t)sq.row0 * a.dv.sn) * 2;
-        const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, seq_range(a.cu, a.dk_range, N, a.dk.sn, D), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, seq_range(a.cu, a.dv_range, N, a.dv.sn, D), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, seq_range(a.cu, a.dk_range, Nk, a.dk.sn, D), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, seq_range(a.cu, a.dv_range, Nk, a.dv.sn, D), 0x00020000);
         typedef __attribute__((ext_vector_type(4))) E e4;
 #pragma unroll
         for (int db = 0; db < DVB; ++db)
@@ -1404,7 +1409,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
     const int head = hk * g + hg * a.hpw + hh;
     const SeqInfo sq = seq_of(a.cu, b, a.N);
     const int N = sq.N, ns = a.num_sink;
-    const int W = a.window < N ? a.window : N;
+    const int P = a.cu ? 0 : a.Nk - a.N;         // position of query row 0 among the keys
+    const int W = a.window < N + P ? a.window : N + P;
     const int BM = 32 * a.rb;
     const int q0 = qt * BM;
     if (q0 >= N) return;   // packed batches: the grid is sized for the longest sequence
@@ -1413,14 +1419,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
     const int qw_hi = (qw0 + 31 < N - 1) ? qw0 + 31 : N - 1;
     const int qrow = qw0 + r;
     const bool wave_live = qw0 < N;
+    const int pw0 = qw0 + P, pw_hi = qw_hi + P;  // the wave's rows as key positions
 
-    const int ns_eff = ns < q1 ? ns : q1;
+    const int ns_eff = ns < q1 + P ? ns : q1 + P;
     const int ts_hi = (ns_eff + 63) >> 6;
-    int wlo = q0 - W + 1;
+    int wlo = q0 + P - W + 1;
     if (wlo < 0) wlo = 0;
     int tw_lo = wlo >> 6;
     if (tw_lo < ts_hi) tw_lo = ts_hi;
-    const int tw_hi = (q1 + 63) >> 6;
+    const int tw_hi = (q1 + P + 63) >> 6;
     if (tw_lo > tw_hi) tw_lo = tw_hi;
     const int nt = ts_hi + (tw_hi - tw_lo);
 
@@ -1505,9 +1512,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
         const int buf = it & 1;
         if (it + 1 < nt) issue_loads(tile_of(it + 1));
         const int k0 = tile_of(it) * 64;
-        const bool needed = wave_live && (k0 <= qw_hi) && (k0 < ns || k0 + 63 >= qw0 - W + 1);
+        const bool needed = wave_live && (k0 <= pw_hi) && (k0 < ns || k0 + 63 >= pw0 - W + 1);
         if (needed) {
-            const bool full = (k0 + 63 <= qw0) && ((k0 + 63 < ns) || (k0 >= qw_hi - W + 1));
+            const bool full = (k0 + 63 <= pw0) && ((k0 + 63 < ns) || (k0 >= pw_hi - W + 1));
             const char* kl = smem + buf * 2 * TILE_BYTES;
             const char* vl = kl + TILE_BYTES;
 #pragma unroll
@@ -1536,7 +1543,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
                         pS[i >> 3][i & 7] = (E)(p * (dP[i] - dlt));
                     }
                 } else {
-                    int qm = qrow;
+                    int qm = qrow + P;
                     asm volatile("; edge tile" : "+v"(qm) : : "memory");     // side effect: the branch cannot be speculated / if-converted
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -2034,7 +2041,8 @@ static size_t consts_bytes(const Problem& p) {
 }
 
 bool bwd_mfma_spill(const Problem& p, unsigned flags) {
-    return (flags & SFA_FLAG_BWD_SPILL_DS) && dkdv_mode() == 3 && p.cu == nullptr && ds_chunks_per_head(p) > 0;
+    return (flags & SFA_FLAG_BWD_SPILL_DS) && dkdv_mode() == 3 && p.cu == nullptr && (p.Nk == 0 || p.Nk == p.N) &&
+           ds_chunks_per_head(p) > 0;
 }
 
 // packed batches are served by the default (wave-specialised) dK/dV kernel only
@@ -2050,13 +2058,13 @@ size_t bwd_mfma_workspace_bytes(const Problem& p, int, unsigned flags) {
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o, const float* lse,
              const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void* workspace,
              const Problem& p, unsigned flags, hipStream_t stream) {
-    if (p.cu && !bwd_mfma_varlen_ok()) {
-        set_error("packed (varlen) backward is served by the default dK/dV kernel only (SFA_DKDV=3)");
+    if ((p.cu || (p.Nk > 0 && p.Nk != p.N)) && !bwd_mfma_varlen_ok()) {
+        set_error("packed (varlen) / N_q != N_kv backward is served by the default dK/dV kernel only (SFA_DKDV=3)");
         return SFA_ERR_UNSUPPORTED;
     }
     if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(d_o) && slice_ok(dq) && slice_ok(dk) && slice_ok(dv))) {
-        if (p.cu) {
-            set_error("packed (varlen) backward needs 16-byte aligned rows and < 4 GiB head slices");
+        if (p.cu || (p.Nk > 0 && p.Nk != p.N)) {
+            set_error("packed (varlen) / N_q != N_kv backward needs 16-byte aligned rows and < 4 GiB head slices");
             return SFA_ERR_UNSUPPORTED;
         }
         return bwd_generic(q, k, v, d_o, lse, delta, dq, dk, dv, p, stream);
@@ -2069,6 +2077,7 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.consts = reinterpret_cast<const float*>(workspace);
     a.cu = p.cu;
     a.n_total = p.n_total;
+    a.Nk = p.cu ? p.N : (p.Nk > 0 ? p.Nk : p.N);
     a.ds = nullptr;
     a.ds_prefix = nullptr;
     a.ds_chunks = 0;
@@ -2083,12 +2092,12 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     }
     a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
     a.num_sink = p.num_sink;
-    a.window = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);
+    a.window = p.window < 0 ? 0 : (p.window > a.Nk ? a.Nk : p.window);
     a.scale = p.scale;
     a.scale_log2 = p.scale * kLog2e;
     a.q_range = slice_range(q); a.k_range = slice_range(k); a.v_range = slice_range(v); a.do_range = slice_range(d_o);
     a.dq_range = slice_range(dq); a.dk_range = slice_range(dk); a.dv_range = slice_range(dv);
-    a.n_kblocks = (int)cdiv64(p.N, kKB);
+    a.n_kblocks = (int)cdiv64(a.Nk, kKB);
     a.hpw = gcd(g, 8);
     a.rb = 8 / a.hpw;
     a.n_qtiles = (int)cdiv64(p.N, 32 * a.rb);

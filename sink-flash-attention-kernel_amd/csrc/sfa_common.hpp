@@ -54,6 +54,7 @@ struct Problem {
     float scale;
     const int* cu = nullptr;
     int n_total = 0;
+    int Nk = 0;          // key rows when they outnumber the query rows (0 = same as N): row i sits at position i + Nk - N
 };
 
 #ifdef __HIPCC__

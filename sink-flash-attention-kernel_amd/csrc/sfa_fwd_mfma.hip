@@ -60,6 +60,7 @@ struct FwdArgs {
     int prio;              // tuning knob (SFA_FWD_PRIO): raised priority for waves 4..7
     const int* cu;         // packed batches: device row offsets [B + 1] (else null), see Problem
     int n_total;           // rows of the packed tensors
+    int Nk;                // key rows (>= N): query row i sits at position i + Nk - N (== N for packed batches)
 };
 
 __device__ __forceinline__ float half_swap_max(float x) {
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
     const int head = hk * g + hg * a.hpw + hh;
     const SeqInfo sq = seq_of(a.cu, b, a.N);
     const int N = sq.N, ns = a.num_sink;
-    const int W = a.window < N ? a.window : N;
+    const int P = a.cu ? 0 : a.Nk - a.N;         // position of query row 0 among the keys
+    const int W = a.window < N + P ? a.window : N + P;
     const int BM = 32 * a.rb;
     const int q0 = qt * BM;
     if (q0 >= N) return;   // packed batches: the grid is sized for the longest sequence
@@ -115,15 +117,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
     const int qw_hi = (qw0 + 31 < N - 1) ? qw0 + 31 : N - 1;
     const int qrow = qw0 + r;
     const bool wave_live = qw0 < N;
+    const int pw0 = qw0 + P, pw_hi = qw_hi + P;  // the wave's rows as key positions
 
     // ---- tile list: sink tiles [0, ts_hi) then window tiles [tw_lo, tw_hi)
-    const int ns_eff = ns < q1 ? ns : q1;
+    const int ns_eff = ns < q1 + P ? ns : q1 + P;
     const int ts_hi = (ns_eff + 63) >> 6;
-    int wlo = q0 - W + 1;
+    int wlo = q0 + P - W + 1;
     if (wlo < 0) wlo = 0;
     int tw_lo = wlo >> 6;
     if (tw_lo < ts_hi) tw_lo = ts_hi;
-    const int tw_hi = (q1 + 63) >> 6;
+    const int tw_hi = (q1 + P + 63) >> 6;
     if (tw_lo > tw_hi) tw_lo = tw_hi;
     const int nt = ts_hi + (tw_hi - tw_lo);
 
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
         const int buf = it & 1;
         if (it + 1 < nt) issue_loads(tile_of(it + 1));
         const int k0 = tile_of(it) * 64;
-        const bool needed = wave_live && (k0 <= qw_hi) && (k0 < ns || k0 + 63 >= qw0 - W + 1);
+        const bool needed = wave_live && (k0 <= pw_hi) && (k0 < ns || k0 + 63 >= pw0 - W + 1);
         if (needed) {
-            const bool full = (k0 + 63 <= qw0) && ((k0 + 63 < ns) || (k0 >= qw_hi - W + 1));
+            const bool full = (k0 + 63 <= pw0) && ((k0 + 63 < ns) || (k0 >= pw_hi - W + 1));
             const char* kl = smem + buf * 2 * TILE_BYTES;
             const char* vl = kl + TILE_BYTES;
             // S^T tiles: rows = 32 keys (two halves), cols = the wave's 32 query rows
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) s[1] = M::run(kfb[ks], qf[ks], s[1]);
             if (!full) {
-                int qm = qrow;
+                int qm = qrow + P;
                 asm volatile("; edge tile" : "+v"(qm) : : "memory");   // side effect: the branch cannot be speculated / if-converted
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
@@ -380,8 +383,8 @@ bool fwd_mfma_supported(int dtype, int D) {
 int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
              const float* s_aux, const Problem& p, hipStream_t stream) {
     if (!(slice_ok(q) && slice_ok(k) && slice_ok(v) && slice_ok(o))) {
-        if (p.cu) {
-            set_error("packed (varlen) forward needs 16-byte aligned rows and < 4 GiB head slices");
+        if (p.cu || (p.Nk > 0 && p.Nk != p.N)) {
+            set_error("packed (varlen) / N_q != N_kv forward needs 16-byte aligned rows and < 4 GiB head slices");
             return SFA_ERR_UNSUPPORTED;
         }
         return fwd_generic(q, k, v, o, lse, s_aux, p, stream);  // unaligned / >4 GiB slices: exact path
@@ -397,8 +400,9 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.lse = lse; a.s_aux = s_aux;
     a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
     a.cu = p.cu; a.n_total = p.n_total;
+    a.Nk = p.cu ? p.N : (p.Nk > 0 ? p.Nk : p.N);
     a.num_sink = p.num_sink;
-    a.window = p.window < 0 ? 0 : (p.window > p.N ? p.N : p.window);
+    a.window = p.window < 0 ? 0 : (p.window > a.Nk ? a.Nk : p.window);
     a.scale_log2 = p.scale * kLog2e;
     a.hpw = gcd(g, NW);
     a.rb = NW / a.hpw;

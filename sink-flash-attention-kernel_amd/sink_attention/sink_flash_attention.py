@@ -37,9 +37,11 @@ class SinkFlashAttentionFunc(torch.autograd.Function):
         N.require_gpu(q, k, v, s_aux)
         B, H_q, Nq, D = q.shape
         H_kv = k.shape[1]
-        # shape contract of the reference (sink_flash_attention.py:494-498)
-        assert k.shape == (B, H_kv, Nq, D)
-        assert v.shape == (B, H_kv, Nq, D)
+        # shape contract of the reference (sink_flash_attention.py:494-498), relaxed in one way: k / v may hold MORE
+        # rows than q; the queries are then the last N_q positions of the key sequence (MFMA kernels only)
+        Nk = k.shape[2]
+        assert k.shape == (B, H_kv, Nk, D) and Nk >= Nq, f"k {tuple(k.shape)} does not fit q {tuple(q.shape)}"
+        assert v.shape == (B, H_kv, Nk, D)
         assert H_q % H_kv == 0
         if q.dtype not in N.SFA_DTYPE or k.dtype != q.dtype or v.dtype != q.dtype:
             raise TypeError(f"q/k/v must share one dtype in (float32, float16, bfloat16); got "
@@ -81,15 +83,15 @@ class SinkFlashAttentionFunc(torch.autograd.Function):
         if do.dtype != q.dtype:
             do = do.to(q.dtype)
         dq = torch.empty((B, H_q, Nq, D), device=q.device, dtype=q.dtype)
-        dk = torch.empty((B, H_kv, Nq, D), device=q.device, dtype=q.dtype)
-        dv = torch.empty((B, H_kv, Nq, D), device=q.device, dtype=q.dtype)
+        dk = torch.empty((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
+        dv = torch.empty((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
         ds_aux = torch.empty((H_q,), device=q.device, dtype=torch.float32) if ctx.use_s_aux else None
         lib = N.lib()
         flags = ctx.flags
         ws_args = (B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink, ctx.window_size)
         ws_bytes = lib.sfa_bwd_workspace_bytes(*ws_args, flags)
         cap = _ds_spill_cap_bytes()
-        if cap > 0 and not (flags & N.FLAG_FORCE_GENERIC):
+        if cap > 0 and not (flags & N.FLAG_FORCE_GENERIC) and k.shape[2] == Nq:
             spill_bytes = lib.sfa_bwd_workspace_bytes(*ws_args, flags | N.FLAG_BWD_SPILL_DS)
             if ws_bytes < spill_bytes <= ws_bytes + cap:
                 flags, ws_bytes = flags | N.FLAG_BWD_SPILL_DS, spill_bytes

@@ -6,7 +6,8 @@ The reference's ``sink_attention/sp_utils.py`` shards the sequence over an SP gr
 the reference cannot work on ranks > 0: it calls ``sink_flash_attention`` with N_q != N_kv (asserted against at
 ``sink_flash_attention.py:494-498``) and a rank never sees the window keys that live on the previous rank.  Here the
 wrapper is REPAIRED: every rank gets the sink keys plus the ``window_size - 1`` keys preceding its chunk (the halo)
-with an autograd-aware all-gather, runs the ordinary kernel on ``[sinks | halo | local]`` and keeps its own rows;
+with an autograd-aware all-gather and runs the kernels with its N_q local queries against the N_kv > N_q keys
+``[sinks | halo | local]`` (query row i sits at key position i + N_kv - N_q);
 gradients of the gathered K/V flow back to their owners through the collective's backward.  Collectives are plain
 ``torch.distributed`` calls (RCCL over xGMI on MI355X, gloo on CPU): this file has no device code.
 """
@@ -95,9 +96,14 @@ def sp_extended_kv(k_full: torch.Tensor, v_full: torch.Tensor, rank: int, n_loca
 
 
 def sp_local_attention(q_local, k_ext, v_ext, lead: int, num_sink: int, window_size: int, s_aux=None):
-    """Attention of the local queries against ``[sinks | halo | local]`` keys: the kernel wants N_q == N_kv, so the
-    ``lead`` key rows without a local query get zero queries whose outputs are dropped."""
+    """Attention of the local queries against ``[sinks | halo | local]`` keys.  The MFMA kernels take N_q < N_kv
+    directly (the queries are the last N_q key positions); shapes they do not cover (fp32, other head dims) get
+    zero queries for the ``lead`` key rows, whose outputs are dropped."""
+    from . import _native as N
     from .sink_flash_attention import _sink_flash_attention_ex
+    if lead and q_local.dtype in (torch.float16, torch.bfloat16) and \
+            N.lib().sfa_varlen_supported(N.SFA_DTYPE[q_local.dtype], q_local.shape[3]) == 1:
+        return _sink_flash_attention_ex(q_local, k_ext, v_ext, num_sink, window_size, s_aux=s_aux)
     if lead:
         q_ext = torch.cat([q_local.new_zeros(q_local.shape[0], q_local.shape[1], lead, q_local.shape[3]), q_local], dim=2)
     else:

@@ -71,3 +71,38 @@ def test_generation_forward_prefill_then_decode_with_cache():
             assert maxdiff(t(o1), r[:, :, -1:]) < 1e-2
     finally:
         unpatch_generation()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Hq,Hkv,D,Nq,Nk,ns,W", [
+    (8, 2, 128, 200, 517, 4, 100),       # window shorter than the lead
+    (4, 4, 64, 64, 1000, 0, 300),        # no sinks, MHA
+    (8, 1, 80, 333, 400, 130, 64),       # sinks longer than a key block, MQA, D=80
+    (4, 2, 96, 1, 257, 2, 10000),        # a single query row, window longer than everything
+    (4, 2, 128, 1024, 1100, 4, 512)])    # many query tiles
+def test_fewer_queries_than_keys_fwd_bwd(dtype, Hq, Hkv, D, Nq, Nk, ns, W):
+    """N_q < N_kv on the MFMA kernels (queries = the last N_q key positions) against the oracle and against the same
+    problem padded with zero queries."""
+    from sink_attention import _native
+    from sink_attention.sink_flash_attention import _sink_flash_attention_ex
+    g = torch.Generator().manual_seed(51)
+    B = 2
+    q, do = rand((B, Hq, Nq, D), g, dtype), rand((B, Hq, Nq, D), g, dtype)
+    k, v = rand((B, Hkv, Nk, D), g, dtype), rand((B, Hkv, Nk, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = _sink_flash_attention_ex(qd, kd, vd, ns, W, s_aux=sad)
+    assert out.shape == (B, Hq, Nq, D) and "mfma" in _native.last_path()
+    out.backward(do.to(DEV))
+    o_r, _ = O.sink_attention_dense(q, k, v, ns, W, sa)
+    dq_r, dk_r, dv_r, dsa_r = O.sink_attention_bwd_dense(q, k, v, do, ns, W, sa)
+    to, tg = (1e-2, 5e-2) if dtype == torch.float16 else (2e-2, 1.5e-1)
+    assert maxdiff(out, o_r) < to
+    assert kd.grad.shape == (B, Hkv, Nk, D)
+    assert maxdiff(qd.grad, dq_r) < tg and maxdiff(kd.grad, dk_r) < tg and maxdiff(vd.grad, dv_r) < tg
+    assert maxdiff(sad.grad, dsa_r) < tg * 10
+    # the padded formulation (zero queries for the leading key rows) gives the same rows
+    qp = torch.cat([torch.zeros(B, Hq, Nk - Nq, D, dtype=dtype), q], dim=2).to(DEV)
+    padded = _sink_flash_attention_ex(qp, kd.detach(), vd.detach(), ns, W, s_aux=sad.detach())[:, :, Nk - Nq:]
+    assert maxdiff(out, padded.double()) < 2e-3
