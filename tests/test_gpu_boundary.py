@@ -81,3 +81,53 @@ def test_c_abi_error_codes():
     with pytest.raises(AssertionError):
         from sink_attention import sink_decode_attention
         sink_decode_attention(torch.zeros(1, 4, 2, 64, device=DEV), k2, k2)   # N_q must be 1
+
+
+def test_ops_run_on_the_current_stream_and_capture_into_a_hip_graph():
+    """The C ABI launches on the stream it is handed and never allocates or synchronises, so the ops work on a side
+    stream and inside torch.cuda.graph capture (hipGraph), forward and backward."""
+    from sink_attention import sink_decode_attention, sink_flash_attention
+    from util import rand
+    g = torch.Generator().manual_seed(61)
+    B, Hq, Hkv, N, D, ns, W = 2, 8, 2, 640, 128, 4, 200
+    q, k, v, do = (rand(s, g, torch.bfloat16).to(DEV) for s in ((B, Hq, N, D), (B, Hkv, N, D), (B, Hkv, N, D), (B, Hq, N, D)))
+    sa = rand((Hq,), g, torch.float32, 0.5).to(DEV)
+    qd, kd, vd, sad = (t.clone().requires_grad_(True) for t in (q, k, v, sa))
+    ref = sink_flash_attention(qd, kd, vd, ns, W, sad)
+    ref.backward(do)
+    ref_g = [t.grad.clone() for t in (qd, kd, vd, sad)]
+    q1 = rand((B, Hq, 1, D), g, torch.bfloat16).to(DEV)
+    ref_dec = sink_decode_attention(q1, k, v, s_aux=sa)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        qs, ks, vs, ss = (t.clone().requires_grad_(True) for t in (q, k, v, sa))
+        for _ in range(2):            # warm-up on the side stream (also what graph capture requires)
+            for t in (qs, ks, vs, ss):
+                t.grad = None
+            out = sink_flash_attention(qs, ks, vs, ns, W, ss)
+            out.backward(do)
+            dec = sink_decode_attention(q1, k, v, s_aux=sa)
+        assert torch.equal(out, ref) and torch.equal(dec, ref_dec)
+        assert all(torch.equal(a.grad, b) for a, b in zip((qs, ks, vs, ss), ref_g))
+        for t in (qs, ks, vs, ss):
+            t.grad = None
+    torch.cuda.current_stream().wait_stream(side)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g = sink_flash_attention(qs, ks, vs, ns, W, ss)
+        out_g.backward(do)
+        dec_g = sink_decode_attention(q1, k, v, s_aux=sa)
+    with torch.no_grad():
+        qs.copy_(q * 0.5)             # new inputs in the captured buffers; the replay must see them
+    graph.replay()
+    torch.cuda.synchronize()
+    q2 = (q * 0.5).clone().requires_grad_(True)
+    k2, v2, s2 = (t.clone().requires_grad_(True) for t in (k, v, sa))
+    exp = sink_flash_attention(q2, k2, v2, ns, W, s2)
+    exp.backward(do)
+    assert torch.equal(out_g, exp) and torch.equal(dec_g, ref_dec)
+    assert torch.equal(qs.grad, q2.grad) and torch.equal(ks.grad, k2.grad) and torch.equal(vs.grad, v2.grad)
+    assert torch.equal(ss.grad, s2.grad)
