@@ -423,514 +423,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel(BwdArgs a) {
         }
 }
 
-// ============================================================ dK / dV, 8 waves
-// Same maths, two waves per SIMD: wave = (key group kg = w & 3: 32 keys) x (row half rh = w >> 2: 32 of the 64 staged
-// query rows).  K/V fragments are read from an LDS image of the block's 128 keys (no register room for them at 256
-// registers per wave); the two row halves of a key group are summed through LDS once, after the sweep.
-template <typename T, int D>
-__global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_w8(BwdArgs a) {
-    using M = Mma<T>;
-    using frag = typename M::frag;
-    using E = typename M::elem;
-    constexpr int DK = D / 16;
-    constexpr int DVB = (D + 31) / 32;
-    constexpr int CPR = D / 8;
-    constexpr int ROWB = (D <= 64) ? 128 : 256;
-    constexpr int QT = 64;
-    constexpr int TILE = QT * ROWB;
-    constexpr int STAGE = 2 * TILE + 512;
-    constexpr int KVT = kKB * ROWB;              // K (or V) image of the block
-    constexpr int NCH = QT * CPR;
-    constexpr int NLD = (NCH + 511) / 512;
-    constexpr int NKV = (kKB * CPR + 511) / 512;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* klds = smem;
-    char* vlds = smem + KVT;
-    char* stage0 = smem + 2 * KVT;
-
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int kb = bid % a.n_kblocks;
-    int rest = bid / a.n_kblocks;
-    const int hk = rest % a.Hkv;
-    const int b = rest / a.Hkv;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave & 3, rh = wave >> 2;
-    const int r = lane & 31, h = lane >> 5;
-    const int N = a.N, W = a.window, ns = a.num_sink;
-    const int g = a.Hq / a.Hkv;
-    const int kb0 = kb * kKB;
-    const int kb1 = (kb0 + kKB < N) ? kb0 + kKB : N;
-    const int kw0 = kb0 + 32 * kg;
-    const int key = kw0 + r;
-
-    const char* kbase = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
-    const char* vbase = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, a.k_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, a.v_range, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NKV; ++i) {
-        const int c = tid + i * 512;
-        const int row = c / CPR, ch = c % CPR;
-        if ((kKB * CPR) % 512 == 0 || c < kKB * CPR) {
-            const unsigned ko = (unsigned)(kb0 + row) * (unsigned)(a.k.sn * 2) + (unsigned)(ch * 16);
-            const unsigned vo = (unsigned)(kb0 + row) * (unsigned)(a.v.sn * 2) + (unsigned)(ch * 16);
-            const u32x4 kx = __builtin_amdgcn_raw_buffer_load_b128(rk, ko, 0, 0);
-            const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
-            const int o = row * ROWB + ((ch ^ sw<ROWB>(row)) << 4);
-            *reinterpret_cast<u32x4*>(klds + o) = kx;
-            *reinterpret_cast<u32x4*>(vlds + o) = vx;
-        }
-    }
-
-    int i_hi;
-    if (kb0 < ns) {
-        i_hi = N;
-    } else {
-        i_hi = kb1 - 1 + W;
-        if (i_hi > N) i_hi = N;
-    }
-    const int qt_lo = kb0 / QT;
-    int qt_hi = (i_hi + QT - 1) / QT;
-    if (qt_hi < qt_lo) qt_hi = qt_lo;
-    const int nq = qt_hi - qt_lo;
-    const int n_it = g * nq;
-
-    f32x16 dKt[DVB], dVt[DVB];
-#pragma unroll
-    for (int db = 0; db < DVB; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dKt[db][i] = 0.f;
-            dVt[db][i] = 0.f;
-        }
-
-    u32x4 qst[NLD], dst[NLD];
-    float cst = 0.f;
-    bool cst_oob = false;
-    auto issue_loads = [&](int it) {
-        const int hh = it / nq, qt = qt_lo + it % nq;
-        const int head = hk * g + hh;
-        const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
-        const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int c = tid + i * 512;
-            const int row = c / CPR, ch = c % CPR;
-            const bool in = (NCH % 512 == 0) || (c < NCH);
-            const unsigned qo = in ? (unsigned)(qt * QT + row) * (unsigned)(a.q.sn * 2) + (unsigned)(ch * 16) : 0xFFFFFFF0u;
-            const unsigned oo = in ? (unsigned)(qt * QT + row) * (unsigned)(a.d_o.sn * 2) + (unsigned)(ch * 16) : 0xFFFFFFF0u;
-            qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, qo, 0, 0);
-            dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, oo, 0, 0);
-        }
-        if (tid < 128) {   // raw value only: converting here would wait a full memory latency inside the loop
-            const int row = qt * QT + (tid & 63);
-            const int64_t idx = ((int64_t)b * a.Hq + head) * N + (row < N ? row : N - 1);
-            cst = (tid < 64) ? a.lse[idx] : a.delta[idx];
-            cst_oob = row >= N;
-        }
-    };
-    auto write_lds = [&](int buf) {
-        char* st = stage0 + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int c = tid + i * 512;
-            const int row = c / CPR, ch = c % CPR;
-            if ((NCH % 512 == 0) || (c < NCH)) {
-                const int o = row * ROWB + ((ch ^ sw<ROWB>(row)) << 4);
-                *reinterpret_cast<u32x4*>(st + o) = qst[i];
-                *reinterpret_cast<u32x4*>(st + TILE + o) = dst[i];
-            }
-        }
-        if (tid < 128)   // -LSE*log2e (rows >= N: -inf => p = 0) | -Delta
-            *reinterpret_cast<float*>(st + 2 * TILE + tid * 4) =
-                (tid < 64) ? (cst_oob ? -INFINITY : -cst * kLog2e) : (cst_oob ? 0.f : -cst);
-    };
-
-    const int rowrd = (32 * rh + r) * ROWB;     // this wave's query row inside the 64-row slice
-    const int krowrd = (32 * kg + r) * ROWB;    // this lane's key row inside the block image
-    const int rsw = sw<ROWB>(r);                // sw(32*x + r) == sw(r)
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    const int tr_row = 32 * rh + 4 * h + q4;
-    const int tr_col = 2 * g1 + (p4 >> 1);
-    const int tr_byte = (p4 & 1) * 8;
-    const float c = a.scale_log2;
-
-    if (n_it > 0) {
-        issue_loads(0);
-        write_lds(0);
-    }
-    __syncthreads();
-
-    for (int it = 0; it < n_it; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < n_it) issue_loads(it + 1);
-        const int q0 = (qt_lo + it % nq) * QT + 32 * rh;   // first query row of this wave's half
-        const bool full = (kw0 + 31 <= q0) && (q0 + 31 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 31));
-        {
-            const char* st = stage0 + buf * STAGE;
-            const char* ql = st;
-            const char* dol = st + TILE;
-            const float* cl = reinterpret_cast<const float*>(st + 2 * TILE);
-            f32x16 S, dP;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                S[i] = 0.f;
-                dP[i] = 0.f;
-            }
-#pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                const int sx = ((2 * ks + h) ^ rsw) << 4;
-                const frag qa = *reinterpret_cast<const frag*>(ql + rowrd + sx);
-                const frag kf = *reinterpret_cast<const frag*>(klds + krowrd + sx);
-                S = M::run(qa, kf, S);
-                const frag da = *reinterpret_cast<const frag*>(dol + rowrd + sx);
-                const frag vf = *reinterpret_cast<const frag*>(vlds + krowrd + sx);
-                dP = M::run(da, vf, dP);
-            }
-            float nl[16], nd[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + 32 * rh + 8 * g4 + 4 * h);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(cl + 64 + 32 * rh + 8 * g4 + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    nl[4 * g4 + e] = l4[e];
-                    nd[4 * g4 + e] = d4[e];
-                }
-            }
-            frag pP[2], pS[2];
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, nl[i]));
-                    pP[i >> 3][i & 7] = (E)p;
-                    pS[i >> 3][i & 7] = (E)(p * (dP[i] + nd[i]));
-                }
-            } else {
-                int keym = key;
-                asm volatile("; edge tile" : "+v"(keym) : : "memory");
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int qi = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const bool valid = (keym <= qi) && (keym < ns || keym + W > qi) && (qi < N);
-                    float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, nl[i]));
-                    p = valid ? p : 0.f;
-                    pP[i >> 3][i & 7] = (E)p;
-                    pS[i >> 3][i & 7] = (E)(p * (dP[i] + nd[i]));
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int db = 0; db < DVB; ++db) {
-                    const int row = 16 * s + tr_row;
-                    const int o1 = row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row)) << 4) + tr_byte;
-                    const int o2 = (row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row + 8)) << 4) + tr_byte;
-                    dVt[db] = M::run(tr_pair2<frag>(dol + o1, dol + o2), pP[s], dVt[db]);
-                    dKt[db] = M::run(tr_pair2<frag>(ql + o1, ql + o2), pS[s], dKt[db]);
-                }
-        }
-        if (it + 1 < n_it) write_lds(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- fold the two row halves through LDS (fixed order => deterministic), then store
-    float* red = reinterpret_cast<float*>(smem);   // [4 key groups][2 (dK,dV)][DVB*16 regs][64 lanes]
-    if (rh == 1) {
-#pragma unroll
-        for (int db = 0; db < DVB; ++db)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                red[((kg * 2 + 0) * DVB * 16 + db * 16 + i) * 64 + lane] = dKt[db][i];
-                red[((kg * 2 + 1) * DVB * 16 + db * 16 + i) * 64 + lane] = dVt[db][i];
-            }
-    }
-    __syncthreads();
-    if (rh == 0) {
-        char* dkb = a.dk.ptr + ((int64_t)b * a.dk.sb + (int64_t)hk * a.dk.sh) * 2;
-        char* dvb = a.dv.ptr + ((int64_t)b * a.dv.sb + (int64_t)hk * a.dv.sh) * 2;
-        const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, a.dk_range, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, a.dv_range, 0x00020000);
-        typedef __attribute__((ext_vector_type(4))) E e4;
-#pragma unroll
-        for (int db = 0; db < DVB; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = 32 * db + 8 * g4 + 4 * h;
-                if (d < D) {
-                    e4 pk, pv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * g4 + e;
-                        const float xk = dKt[db][i] + red[((kg * 2 + 0) * DVB * 16 + db * 16 + i) * 64 + lane];
-                        const float xv = dVt[db][i] + red[((kg * 2 + 1) * DVB * 16 + db * 16 + i) * 64 + lane];
-                        pk[e] = (E)(xk * a.scale);
-                        pv[e] = (E)xv;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rdk,
-                                                          (unsigned)key * (unsigned)(a.dk.sn * 2) + (unsigned)(d * 2), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), rdv,
-                                                          (unsigned)key * (unsigned)(a.dv.sn * 2) + (unsigned)(d * 2), 0, 0);
-                }
-            }
-    }
-}
-
-// ==================================================== dK / dV, software pipelined
-// One wave per SIMD cannot hide its exp/pack VALU phase behind another wave, so the loop is skewed by one slice:
-// trip t issues the S/dP MFMAs of slice t+1, converts slice t's scores (VALU, independent of those MFMAs) and then
-// runs slice t's dV/dK MFMAs -- one basic block per trip so the scheduler can interleave matrix and vector work.
-// Three LDS stages: slice t (transposed reads), t+1 (row reads), t+2 (being staged).
-template <typename T, int D>
-__global__ __launch_bounds__(256, 1) void bwd_dkdv_mfma_kernel_p(BwdArgs a) {
-    using M = Mma<T>;
-    using frag = typename M::frag;
-    using E = typename M::elem;
-    constexpr int DK = D / 16;
-    constexpr int DVB = (D + 31) / 32;
-    constexpr int CPR = D / 8;
-    constexpr int ROWB = (D <= 64) ? 128 : 256;
-    constexpr int QT = 64;
-    constexpr int TILE = QT * ROWB;
-    constexpr int STAGE = 2 * TILE + 512;
-    constexpr int NCH = QT * CPR;
-    constexpr int NLD = (NCH + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int kb = bid % a.n_kblocks;
-    int rest = bid / a.n_kblocks;
-    const int hk = rest % a.Hkv;
-    const int b = rest / a.Hkv;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int N = a.N, W = a.window, ns = a.num_sink;
-    const int g = a.Hq / a.Hkv;
-    const int kb0 = kb * kKB;
-    const int kb1 = (kb0 + kKB < N) ? kb0 + kKB : N;
-    const int kw0 = kb0 + 32 * wave;
-    const int key = kw0 + r;
-
-    const char* kbase = a.k.ptr + ((int64_t)b * a.k.sb + (int64_t)hk * a.k.sh) * 2;
-    const char* vbase = a.v.ptr + ((int64_t)b * a.v.sb + (int64_t)hk * a.v.sh) * 2;
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, a.k_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, a.v_range, 0x00020000);
-    frag kf[DK], vf[DK];
-#pragma unroll
-    for (int ks = 0; ks < DK; ++ks) {
-        const unsigned ko = (unsigned)key * (unsigned)(a.k.sn * 2) + (unsigned)((2 * ks + h) * 16);
-        const unsigned vo = (unsigned)key * (unsigned)(a.v.sn * 2) + (unsigned)((2 * ks + h) * 16);
-        kf[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rk, ko, 0, 0));
-        vf[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0));
-    }
-    // loop-invariant MFMA B operands: pin them in the accumulator half of the register file (frees 64 VGPRs)
-#pragma unroll
-    for (int ks = 0; ks < DK; ++ks) {
-        u32x4 kx = __builtin_bit_cast(u32x4, kf[ks]), vx = __builtin_bit_cast(u32x4, vf[ks]);
-        asm volatile("" : "+a"(kx), "+a"(vx));
-        kf[ks] = __builtin_bit_cast(frag, kx);
-        vf[ks] = __builtin_bit_cast(frag, vx);
-    }
-
-    int i_hi;
-    if (kb0 < ns) {
-        i_hi = N;
-    } else {
-        i_hi = kb1 - 1 + W;
-        if (i_hi > N) i_hi = N;
-    }
-    const int qt_lo = kb0 / QT;
-    int qt_hi = (i_hi + QT - 1) / QT;
-    if (qt_hi < qt_lo) qt_hi = qt_lo;
-    const int nq = qt_hi - qt_lo;
-    const int n_it = g * nq;
-
-    f32x16 dKt[DVB], dVt[DVB];
-#pragma unroll
-    for (int db = 0; db < DVB; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dKt[db][i] = 0.f;
-            dVt[db][i] = 0.f;
-        }
-
-    // Q/dO slices go global -> LDS directly (buffer_load ... lds, no staging registers): a wave instruction fills
-    // 1 KiB of the image linearly, so the XOR swizzle is applied to the per-lane SOURCE chunk instead.
-    constexpr int CPRD = ROWB / 16;                  // 16-byte slots per image row
-    constexpr int NDMA = QT * CPRD / 256;
-    float cst = 0.f;
-    bool cst_oob = false;
-    auto stage_dma = [&](int it, int stage) {
-        const int hh = it / nq, qt = qt_lo + it % nq;
-        const int head = hk * g + hh;
-        const char* qb = a.q.ptr + ((int64_t)b * a.q.sb + (int64_t)head * a.q.sh) * 2;
-        const char* dob = a.d_o.ptr + ((int64_t)b * a.d_o.sb + (int64_t)head * a.d_o.sh) * 2;
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, a.q_range, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, a.do_range, 0x00020000);
-        char* st = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int c = i * 256 + tid;
-            const int row = c / CPRD, ch = (c % CPRD) ^ sw<ROWB>(row);
-            const bool in = ch < CPR;
-            const unsigned qo = in ? (unsigned)(qt * QT + row) * (unsigned)(a.q.sn * 2) + (unsigned)(ch * 16) : 0xFFFFFFF0u;
-            const unsigned oo = in ? (unsigned)(qt * QT + row) * (unsigned)(a.d_o.sn * 2) + (unsigned)(ch * 16) : 0xFFFFFFF0u;
-            char* dstq = st + (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)dstq, 16, qo, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dstq + TILE), 16, oo, 0, 0, 0);
-        }
-        if (tid < 128) {   // raw value only: converting here would wait a full memory latency inside the loop
-            const int row = qt * QT + (tid & 63);
-            const int64_t idx = ((int64_t)b * a.Hq + head) * N + (row < N ? row : N - 1);
-            cst = (tid < 64) ? a.lse[idx] : a.delta[idx];
-            cst_oob = row >= N;
-        }
-    };
-    auto write_consts = [&](int stage) {
-        if (tid < 128)
-            *reinterpret_cast<float*>(smem + stage * STAGE + 2 * TILE + tid * 4) =
-                (tid < 64) ? (cst_oob ? -INFINITY : -cst * kLog2e) : (cst_oob ? 0.f : -cst);
-    };
-
-    const int rowrd = r * ROWB;
-    const int rsw = sw<ROWB>(r);
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    const int tr_row = 4 * h + q4;
-    const int tr_col = 2 * g1 + (p4 >> 1);
-    const int tr_byte = (p4 & 1) * 8;
-    const float c = a.scale_log2;
-
-    // phase A of one 32-row half: S = Q K^T, dP = dO V^T (16 MFMAs)
-    auto phase_a = [&](const char* st, int sub, f32x16& S, f32x16& dP) {
-        const char* ql = st;
-        const char* dol = st + TILE;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            S[i] = 0.f;
-            dP[i] = 0.f;
-        }
-#pragma unroll
-        for (int ks = 0; ks < DK; ++ks) {
-            const int o = sub * 32 * ROWB + rowrd + (((2 * ks + h) ^ rsw) << 4);
-            const frag qa = *reinterpret_cast<const frag*>(ql + o);
-            const frag da = *reinterpret_cast<const frag*>(dol + o);
-            S = M::run(qa, kf[ks], S);
-            dP = M::run(da, vf[ks], dP);
-        }
-    };
-    // VALU of one half: P = exp2(c*S - LSE*log2e), dS = P*(dP - Delta), packed as B operands
-    auto phase_v = [&](auto full_tag, const char* st, int q0, int sub, const f32x16& S, const f32x16& dP,
-                       frag (&pP)[2], frag (&pS)[2]) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const float* cl = reinterpret_cast<const float*>(st + 2 * TILE);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + 32 * sub + 8 * g4 + 4 * h);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(cl + 64 + 32 * sub + 8 * g4 + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * g4 + e;
-                float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, l4[e]));
-                if constexpr (!FULL) {
-                    const int qi = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const bool valid = (key <= qi) && (key < ns || key + W > qi) && (qi < N);
-                    p = valid ? p : 0.f;
-                }
-                pP[i >> 3][i & 7] = (E)p;
-                pS[i >> 3][i & 7] = (E)(p * (dP[i] + d4[e]));
-            }
-        }
-    };
-    // phase C of a slice: dV^T += dO^T P ; dK^T += Q^T dS (32 MFMAs)
-    auto phase_c = [&](const char* st, const frag (&pP)[2][2], const frag (&pS)[2][2]) {
-        const char* ql = st;
-        const char* dol = st + TILE;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int db = 0; db < DVB; ++db) {
-                    const int row = 32 * sub + 16 * s + tr_row;
-                    const int o1 = row * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row)) << 4) + tr_byte;
-                    const int o2 = (row + 8) * ROWB + (((4 * db + tr_col) ^ sw<ROWB>(row + 8)) << 4) + tr_byte;
-                    dVt[db] = M::run(tr_pair2<frag>(dol + o1, dol + o2), pP[sub][s], dVt[db]);
-                    dKt[db] = M::run(tr_pair2<frag>(ql + o1, ql + o2), pS[sub][s], dKt[db]);
-                }
-    };
-    // one trip: per half, convert slice t's scores then issue slice t+1's S/dP MFMAs into the same registers;
-    // then slice t's dV/dK MFMAs.  One basic block per trip variant.
-    f32x16 S[2], dP[2];
-    auto trip = [&](int t) {
-        if (t + 2 < n_it) stage_dma(t + 2, (t + 2) % 3);
-        const char* st_t = smem + (t % 3) * STAGE;
-        const char* st_n = smem + ((t + 1) % 3) * STAGE;
-        const int q0 = (qt_lo + t % nq) * QT;
-        const bool full = (kw0 + 31 <= q0) && (q0 + 63 < N) && ((kw0 + 31 < ns) || (kw0 + W > q0 + 63));
-        frag pP[2][2], pS[2][2];
-        if (full) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                phase_v(std::true_type{}, st_t, q0, sub, S[sub], dP[sub], pP[sub], pS[sub]);
-                phase_a(st_n, sub, S[sub], dP[sub]);   // slice t+1 (past the end: allocated stage, result unused)
-            }
-            phase_c(st_t, pP, pS);
-        } else {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                phase_v(std::false_type{}, st_t, q0, sub, S[sub], dP[sub], pP[sub], pS[sub]);
-                phase_a(st_n, sub, S[sub], dP[sub]);
-            }
-            phase_c(st_t, pP, pS);
-        }
-        if (t + 2 < n_it) write_consts((t + 2) % 3);
-        __syncthreads();
-    };
-
-    if (n_it > 0) {
-        stage_dma(0, 0);
-        write_consts(0);
-        if (n_it > 1) {
-            stage_dma(1, 1);
-            write_consts(1);
-        }
-    }
-    __syncthreads();
-    if (n_it > 0) {
-        phase_a(smem, 0, S[0], dP[0]);
-        phase_a(smem, 1, S[1], dP[1]);
-    }
-    for (int t = 0; t < n_it; ++t) trip(t);
-
-    char* dkb = a.dk.ptr + ((int64_t)b * a.dk.sb + (int64_t)hk * a.dk.sh) * 2;
-    char* dvb = a.dv.ptr + ((int64_t)b * a.dv.sb + (int64_t)hk * a.dv.sh) * 2;
-    const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)dkb, 0, a.dk_range, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc((void*)dvb, 0, a.dv_range, 0x00020000);
-    typedef __attribute__((ext_vector_type(4))) E e4;
-#pragma unroll
-    for (int db = 0; db < DVB; ++db)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d = 32 * db + 8 * g4 + 4 * h;
-            if (d < D) {
-                e4 pk, pv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pk[e] = (E)(dKt[db][4 * g4 + e] * a.scale);
-                    pv[e] = (E)(dVt[db][4 * g4 + e]);
-                }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rdk,
-                                                      (unsigned)key * (unsigned)(a.dk.sn * 2) + (unsigned)(d * 2), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), rdv,
-                                                      (unsigned)key * (unsigned)(a.dv.sn * 2) + (unsigned)(d * 2), 0, 0);
-            }
-        }
-}
-
 // ================================================ dK / dV, wave-specialised (8 waves)
 // Two waves per SIMD without blowing the register budget: the work of a 32-key group is split by ROLE.
 //   score wave  (waves 0-3): S = Q K^T, dP = dO V^T (16 MFMAs per 32-row slice), P = exp2(..), dS = P*(dP-Delta),
@@ -1889,11 +1381,11 @@ size_t ds_table_bytes(const Problem& p) { return (((size_t)cdiv64(p.N, kKB) + 1)
 template <typename T, int D>
 int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
     constexpr int ROWB = (D <= 64) ? 128 : 256;
-    // dK/dV variant (C3, ms): 3 = wave-specialised score/accumulate waves, 2 per SIMD (default, 4.1);
-    // 0 = 4 waves, one per SIMD (5.0); 1 = 8 identical waves with K/V from LDS (LDS-bound, 7.4);
-    // 2 = 4 waves software-pipelined (register-starved under hipcc 7.2, 6.8)
+    // dK/dV variant (SFA_DKDV; C3, ms): 3 = wave-specialised score/accumulate waves, 2 per SIMD (default, 3.6);
+    // anything else = the plain kernel, 4 waves, one per SIMD (5.0).  Two more variants were measured and removed:
+    // 8 identical waves with K/V fragments from LDS (LDS-bound, 7.4) and a software-pipelined 4-wave kernel
+    // (register-starved under hipcc 7.2, 6.8).
     const int mode = dkdv_mode();
-    const int use_w8 = mode == 1;
     if (mode == 3) {
         {
             const int rows = a.cu ? a.n_total : a.N;                  // packed batches: one [Hq, n_total] slab
@@ -1954,30 +1446,6 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
         kern<<<dim3(nblk), dim3(512), lds, stream>>>(a);
         int st = launch_status("bwd_dkdv_mfma_ws");
         if (st) return st;
-    } else if (mode == 2) {
-        constexpr int lds = 3 * (2 * 64 * ROWB + 512);
-        auto kern = bwd_dkdv_mfma_kernel_p<T, D>;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
-        const int nblk = a.n_kblocks * a.Hkv * B;
-        kern<<<dim3(nblk), dim3(256), lds, stream>>>(a);
-        int st = launch_status("bwd_dkdv_mfma_p");
-        if (st) return st;
-    } else if (use_w8) {
-        constexpr int lds = 2 * kKB * ROWB + 2 * (2 * 64 * ROWB + 512);
-        auto kern = bwd_dkdv_mfma_kernel_w8<T, D>;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
-        const int nblk = a.n_kblocks * a.Hkv * B;
-        kern<<<dim3(nblk), dim3(512), lds, stream>>>(a);
-        int st = launch_status("bwd_dkdv_mfma_w8");
-        if (st) return st;
     } else {
         constexpr int lds = 2 * (2 * 64 * ROWB + 512);
         auto kern = bwd_dkdv_mfma_kernel<T, D>;
@@ -2004,7 +1472,7 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
         const int nblk = a.n_qtiles * a.hgroups * a.Hkv * B;
         kern<<<dim3(nblk), dim3(NW * 64), lds, stream>>>(a);
     }
-    set_path("bwd_mfma_%s_d%d_dkdv%s_dq8w_hpw%d", DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, mode == 3 ? "ws8" : (mode == 2 ? "4wp" : (use_w8 ? "8w" : "4w")), a.hpw);
+    set_path("bwd_mfma_%s_d%d_dkdv%s_dq8w_hpw%d", DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, mode == 3 ? "ws8" : "4w", a.hpw);
     return launch_status("bwd_dq_mfma");
 }
 
