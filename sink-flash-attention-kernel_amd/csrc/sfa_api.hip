@@ -176,11 +176,14 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     float* delta = reinterpret_cast<float*>((char*)workspace + w.delta_off);
     float* dsaux_part = reinterpret_cast<float*>((char*)workspace + w.dsaux_off);
     record_stage(0, s);
-    st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s);
+    // the row constants of the dK/dV kernel come out of the same pass whenever it is the vectorised one
+    const bool fuse = use_mfma && bwd_mfma_wants_consts() && bwd_preprocess_vectorised(o, d_o, p);
+    st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s,
+                        fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr);
     record_stage(1, s);
     if (st) return st;
     if (use_mfma)
-        st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, flags, s);
+        st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, p, flags, s, fuse);
     else if (p.Nk != p.N) {
         set_error("N_q != N_kv is served by the MFMA kernels only (16-bit dtypes, head dims 64/80/96/128)");
         st = SFA_ERR_UNSUPPORTED;
@@ -259,10 +262,12 @@ int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v
     float* delta = reinterpret_cast<float*>((char*)workspace + w.delta_off);
     float* dsaux_part = reinterpret_cast<float*>((char*)workspace + w.dsaux_off);
     record_stage(0, s);
-    st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s);   // row-wise: no sequence structure
+    const bool fuse = bwd_mfma_wants_consts() && bwd_preprocess_vectorised(o, d_o, p);
+    st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s,           // row-wise: no sequence structure
+                        fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr);
     record_stage(1, s);
     if (st) return st;
-    st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, run, 0, s);
+    st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, run, 0, s, fuse);
     record_stage(3, s);
     return st;
 }

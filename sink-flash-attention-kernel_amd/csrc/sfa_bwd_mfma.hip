@@ -89,6 +89,7 @@ struct BwdArgs {
     const int* cu;                   // packed batches: device row offsets [B + 1] (else null), see Problem
     int n_total;                     // rows of the packed tensors
     int Nk;                          // key rows (>= N): query row i sits at position i + Nk - N
+    int consts_ready;                // the preprocess pass already wrote the row constants
     int ds_nt;                       // tuning knob (SFA_DS_NT): non-temporal hint on the dS stream loads of the dQ GEMM
     int64_t ds_chunks;               // chunks per head = ds_prefix[n_kblocks]
 };
@@ -1387,7 +1388,7 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
     // (register-starved under hipcc 7.2, 6.8).
     const int mode = dkdv_mode();
     if (mode == 3) {
-        {
+        if (!a.consts_ready) {
             const int rows = a.cu ? a.n_total : a.N;                  // packed batches: one [Hq, n_total] slab
             const int64_t total = (a.cu ? 1 : (int64_t)B) * a.Hq * rows;
             bwd_consts_kernel<<<dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream>>>(
@@ -1515,6 +1516,7 @@ bool bwd_mfma_spill(const Problem& p, unsigned flags) {
 
 // packed batches are served by the default (wave-specialised) dK/dV kernel only
 bool bwd_mfma_varlen_ok() { return dkdv_mode() == 3; }
+bool bwd_mfma_wants_consts() { return dkdv_mode() == 3; }
 
 size_t bwd_mfma_workspace_bytes(const Problem& p, int, unsigned flags) {
     size_t n = consts_bytes(p);
@@ -1525,7 +1527,7 @@ size_t bwd_mfma_workspace_bytes(const Problem& p, int, unsigned flags) {
 
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o, const float* lse,
              const float* delta, const sfa_tensor* dq, const sfa_tensor* dk, const sfa_tensor* dv, void* workspace,
-             const Problem& p, unsigned flags, hipStream_t stream) {
+             const Problem& p, unsigned flags, hipStream_t stream, bool consts_ready) {
     if ((p.cu || (p.Nk > 0 && p.Nk != p.N)) && !bwd_mfma_varlen_ok()) {
         set_error("packed (varlen) / N_q != N_kv backward is served by the default dK/dV kernel only (SFA_DKDV=3)");
         return SFA_ERR_UNSUPPORTED;
@@ -1543,6 +1545,7 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.dq = make_view(dq); a.dk = make_view(dk); a.dv = make_view(dv);
     a.lse = lse; a.delta = delta;
     a.consts = reinterpret_cast<const float*>(workspace);
+    a.consts_ready = consts_ready ? 1 : 0;
     a.cu = p.cu;
     a.n_total = p.n_total;
     a.Nk = p.cu ? p.N : (p.Nk > 0 ? p.Nk : p.N);

@@ -167,6 +167,73 @@ __global__ __launch_bounds__(256) void bwd_preprocess_kernel(View o, View d_o, c
     }
 }
 
+// Same contract for 16-bit tensors with 16-byte aligned rows (every MFMA-path call): a row is spread over LPR lanes
+// x 16 bytes, so one wave instruction fetches 64 / LPR whole rows (1 KiB, coalesced) and all of a wave's 16 rows of O
+// and dO are in flight at once.  HBM-bound: reads O and dO once.  Optionally also emits the row constants of the
+// wave-specialised dK/dV kernel (consts[b,h,0,:] = -LSE*log2e, consts[b,h,1,:] = -Delta) instead of a separate pass.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void bwd_preprocess_vec_kernel(View o, View d_o, const float* __restrict__ lse,
+                                                                const float* __restrict__ s_aux,
+                                                                float* __restrict__ delta,
+                                                                float* __restrict__ dsaux_part,
+                                                                float* __restrict__ consts, Problem p) {
+    constexpr int RPI = 64 / LPR;                      // rows per wave instruction
+    constexpr int NI = (kPreRows / kWaves) / RPI;      // instructions per wave (16 rows)
+    __shared__ float part[kWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int chunk = lane % LPR, rsub = lane / LPR;
+    const bool cact = chunk * 8 < p.D;
+    const char* ob = o.ptr + ((int64_t)b * o.sb + (int64_t)h * o.sh) * 2 + (cact ? chunk * 16 : 0);
+    const char* dob = d_o.ptr + ((int64_t)b * d_o.sb + (int64_t)h * d_o.sh) * 2 + (cact ? chunk * 16 : 0);
+    const int64_t rowbase = ((int64_t)b * p.Hq + h) * p.N;
+    const int row0 = blockIdx.x * kPreRows + wave * (kPreRows / kWaves) + rsub;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    u4 xo[NI], xd[NI];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int i = row0 + t * RPI;
+        const int ic = i < p.N ? i : p.N - 1;
+        xo[t] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(ob + (int64_t)ic * o.sn * 2));
+        xd[t] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(dob + (int64_t)ic * d_o.sn * 2));
+    }
+    const float sa = s_aux ? s_aux[h] : 0.f;
+    float wsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int i = row0 + t * RPI;
+        const unsigned ow[4] = {xo[t][0], xo[t][1], xo[t][2], xo[t][3]}, dw[4] = {xd[t][0], xd[t][1], xd[t][2], xd[t][3]};
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s = fmaf(raw16_to_f32<T>((unsigned short)(ow[e] & 0xffffu)), raw16_to_f32<T>((unsigned short)(dw[e] & 0xffffu)), s);
+            s = fmaf(raw16_to_f32<T>((unsigned short)(ow[e] >> 16)), raw16_to_f32<T>((unsigned short)(dw[e] >> 16)), s);
+        }
+        if (!cact) s = 0.f;
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+        if (i < p.N && chunk == 0) {
+            delta[rowbase + i] = s;
+            const float ls = lse[rowbase + i];
+            if (consts) {
+                consts[rowbase * 2 + i] = -ls * kLog2e;
+                consts[rowbase * 2 + p.N + i] = -s;
+            }
+            if (s_aux) wsum -= expf(sa - ls) * s;
+        }
+    }
+    if (s_aux) {
+        wsum = wave_sum(wsum);
+        if (lane == 0) part[wave] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < kWaves; ++w) t += part[w];
+            dsaux_part[((int64_t)b * p.Hq + h) * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
 // ds_aux[h] = sum over (b, blk) of the partials, fixed order => deterministic
 __global__ __launch_bounds__(256) void dsaux_reduce_kernel(const float* __restrict__ part, float* __restrict__ ds_aux,
                                                           int B, int Hq, int nblk) {
@@ -381,14 +448,39 @@ int fwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, c
     return launch_status("fwd_generic");
 }
 
+static bool rows16(const sfa_tensor* t) {
+    return ((uintptr_t)t->ptr % 16) == 0 && (t->stride[0] * 2) % 16 == 0 && (t->stride[1] * 2) % 16 == 0 &&
+           (t->stride[2] * 2) % 16 == 0;
+}
+
+bool bwd_preprocess_vectorised(const sfa_tensor* o, const sfa_tensor* d_o, const Problem& p) {
+    return o->dtype != SFA_DTYPE_F32 && p.D % 8 == 0 && p.D <= 128 && rows16(o) && rows16(d_o);
+}
+
 int bwd_preprocess(const sfa_tensor* o, const sfa_tensor* d_o, const float* lse, const float* s_aux, float* delta,
-                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream) {
+                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream, float* consts) {
     const int nblk = (int)cdiv64(p.N, kPreRows);
     dim3 grid(nblk, p.Hq, p.B), block(256);
-    SFA_DISPATCH_DTYPE(o->dtype, [&] {
-        bwd_preprocess_kernel<T><<<grid, block, 0, stream>>>(make_view(o), make_view(d_o), lse, s_aux, delta,
-                                                            dsaux_part, p);
-    });
+    const bool vec = bwd_preprocess_vectorised(o, d_o, p);
+    if (vec) {
+        const int lpr = p.D <= 32 ? 4 : (p.D <= 64 ? 8 : 16);
+#define SFA_PRE(TT, L) bwd_preprocess_vec_kernel<TT, L><<<grid, block, 0, stream>>>(make_view(o), make_view(d_o), lse, s_aux, delta, dsaux_part, consts, p)
+        if (o->dtype == SFA_DTYPE_BF16) {
+            if (lpr == 4) SFA_PRE(bf16_t, 4); else if (lpr == 8) SFA_PRE(bf16_t, 8); else SFA_PRE(bf16_t, 16);
+        } else {
+            if (lpr == 4) SFA_PRE(f16_t, 4); else if (lpr == 8) SFA_PRE(f16_t, 8); else SFA_PRE(f16_t, 16);
+        }
+#undef SFA_PRE
+    } else {
+        if (consts) {
+            set_error("bwd_preprocess: the row constants need the vectorised path");
+            return SFA_ERR_UNSUPPORTED;
+        }
+        SFA_DISPATCH_DTYPE(o->dtype, [&] {
+            bwd_preprocess_kernel<T><<<grid, block, 0, stream>>>(make_view(o), make_view(d_o), lse, s_aux, delta,
+                                                                dsaux_part, p);
+        });
+    }
     int st = launch_status("bwd_preprocess");
     if (st != SFA_OK) return st;
     if (s_aux) {

@@ -7,8 +7,11 @@ namespace sfa {
 // sfa_generic.hip
 int fwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o, float* lse,
                 const float* s_aux, const Problem& p, hipStream_t stream);
+// consts (optional, 16-bit tensors with 16-byte aligned rows only): [B, Hq, 2, N] row constants of the wave-specialised
+// dK/dV kernel, written in the same pass
 int bwd_preprocess(const sfa_tensor* o, const sfa_tensor* d_o, const float* lse, const float* s_aux, float* delta,
-                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream);
+                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream, float* consts = nullptr);
+bool bwd_preprocess_vectorised(const sfa_tensor* o, const sfa_tensor* d_o, const Problem& p);   // can it emit consts?
 int64_t bwd_preprocess_nblk(int64_t N);
 int bwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
                 const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,
@@ -24,7 +27,9 @@ bool bwd_mfma_supported(int dtype, int D);
 size_t bwd_mfma_workspace_bytes(const Problem& p, int dtype, unsigned flags);
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
              const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,
-             const sfa_tensor* dv, void* workspace, const Problem& p, unsigned flags, hipStream_t stream);
+             const sfa_tensor* dv, void* workspace, const Problem& p, unsigned flags, hipStream_t stream,
+             bool consts_ready = false);
+bool bwd_mfma_wants_consts();   // the default dK/dV kernel reads the row constants from the head of its workspace
 
 // sfa_decode.hip
 struct DecodePlan {
