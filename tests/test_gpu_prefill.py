@@ -393,3 +393,34 @@ def test_ds_spill_backward_matches_recompute(monkeypatch, B, Hq, Hkv, N, D, ns, 
     assert torch.equal(res["0"][1], res["8"][1]) and torch.equal(res["0"][2], res["8"][2])
     assert torch.equal(res["0"][3], res["8"][3])
     assert maxdiff(res["0"][0], res["8"][0].double()) < 2e-3
+
+
+def test_very_long_sequence_and_chunked_tail():
+    """N = 65536 (offsets far beyond 16 bits, 1024 key tiles): forward against the banded oracle, forward+backward
+    finite, and the last 8192 queries run alone against all keys (N_q < N_kv) reproduce the tail of the full run."""
+    from sink_attention import _native, sink_flash_attention
+    from sink_attention.sink_flash_attention import _sink_flash_attention_ex
+    g = torch.Generator().manual_seed(123)
+    B, Hq, Hkv, N, D, ns, W = 1, 4, 1, 65536, 128, 4, 4096
+    q, k, v = rand((B, Hq, N, D), g, torch.bfloat16), rand((B, Hkv, N, D), g, torch.bfloat16), rand(
+        (B, Hkv, N, D), g, torch.bfloat16)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = sink_flash_attention(qd, kd, vd, ns, W, sad)
+    assert "mfma" in _native.last_path()
+    out.float().sum().backward()
+    for t in (out, qd.grad, kd.grad, vd.grad, sad.grad):
+        assert torch.isfinite(t).all()
+    # oracle on two windows of rows (head 1): fp64 masked softmax over just the keys those rows can see
+    from oracle import sink_oracle as O
+    for r0 in (0, N - 512):
+        rows = torch.arange(r0, r0 + 512)
+        cols = torch.cat([torch.arange(0, min(ns, r0 + 512)), torch.arange(max(r0 - W + 1, ns, 0), r0 + 512)])
+        s = (q[0, 1, rows].double() @ k[0, 0, cols].double().T) / D ** 0.5
+        s = s.masked_fill(~O.valid_mask(rows, cols, ns, W), float("-inf"))
+        lse = torch.logsumexp(torch.cat([s, sa[1].double().expand(512, 1)], dim=1), dim=1, keepdim=True)
+        o_r = torch.exp(s - lse) @ v[0, 0, cols].double()
+        assert maxdiff(out[0, 1, r0:r0 + 512], o_r) < 2e-2
+    tail = _sink_flash_attention_ex(qd.detach()[:, :, N - 8192:], kd.detach(), vd.detach(), ns, W, s_aux=sad.detach())
+    assert torch.equal(tail, out.detach()[:, :, N - 8192:])
