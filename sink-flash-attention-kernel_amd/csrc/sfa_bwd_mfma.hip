@@ -1461,7 +1461,31 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
         if (st) return st;
     }
     record_stage(2, stream);
-    {
+    // dQ kernel: forward-shaped, same choice of workgroup size as the forward (short window -> two 4-wave workgroups
+    // per CU instead of one 8-wave workgroup)
+    static const int dq_nw_env = [] {
+        const char* e = getenv("SFA_DQ_NW");
+        return e ? atoi(e) : 0;
+    }();
+    const int dq_nw = (dq_nw_env == 4 || dq_nw_env == 8) ? dq_nw_env : (a.window <= 2048 ? 4 : 8);
+    if (dq_nw == 4) {
+        constexpr int NW = 4;
+        constexpr int lds = 2 * 2 * 64 * ROWB;
+        BwdArgs a4 = a;
+        const int g = a.Hq / a.Hkv;
+        a4.hpw = g % 4 == 0 ? 4 : (g % 2 == 0 ? 2 : 1);
+        a4.rb = NW / a4.hpw;
+        a4.n_qtiles = (int)cdiv64(a.N, 32 * a4.rb);
+        a4.hgroups = g / a4.hpw;
+        auto kern = bwd_dq_mfma_kernel<T, D, NW>;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        const int64_t nblk = (int64_t)a4.n_qtiles * a4.hgroups * a.Hkv * B;
+        kern<<<dim3((unsigned)nblk), dim3(NW * 64), lds, stream>>>(a4);
+    } else {
         constexpr int NW = 8;
         constexpr int lds = 2 * 2 * 64 * ROWB;
         auto kern = bwd_dq_mfma_kernel<T, D, NW>;
@@ -1473,7 +1497,7 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
         const int nblk = a.n_qtiles * a.hgroups * a.Hkv * B;
         kern<<<dim3(nblk), dim3(NW * 64), lds, stream>>>(a);
     }
-    set_path("bwd_mfma_%s_d%d_dkdv%s_dq8w_hpw%d", DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, mode == 3 ? "ws8" : "4w", a.hpw);
+    set_path("bwd_mfma_%s_d%d_dkdv%s_dq%dw_hpw%d", DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, mode == 3 ? "ws8" : "4w", dq_nw, a.hpw);
     return launch_status("bwd_dq_mfma");
 }
 
