@@ -83,9 +83,11 @@ class SinkFlashAttentionFunc(torch.autograd.Function):
         if do.dtype != q.dtype:
             do = do.to(q.dtype)
         dq = torch.empty((B, H_q, Nq, D), device=q.device, dtype=q.dtype)
-        dk = torch.empty((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
-        dv = torch.empty((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
-        ds_aux = torch.empty((H_q,), device=q.device, dtype=torch.float32) if ctx.use_s_aux else None
+        # no query rows (possible with N_q < N_kv): nothing is launched, the key gradients are exactly zero
+        mk = torch.zeros if (Nq == 0 or B == 0 or H_q == 0) else torch.empty
+        dk = mk((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
+        dv = mk((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
+        ds_aux = mk((H_q,), device=q.device, dtype=torch.float32) if ctx.use_s_aux else None
         lib = N.lib()
         flags = ctx.flags
         ws_args = (B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink, ctx.window_size)
