@@ -14,7 +14,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfa.so")
+LIB_PATH = os.environ.get("SFA_LIB_PATH") or os.path.join(_HERE, "libsfa.so")   # env: A/B builds in development
 
 SFA_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 FLAG_FORCE_GENERIC = 0x1
