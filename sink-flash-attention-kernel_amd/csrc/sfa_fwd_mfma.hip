@@ -260,7 +260,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kh][i]);
             mx = half_swap_max(mx);
-            const float m_new = fmaxf(m, mx * c);
+            // Deferred rescale: keep the old reference point unless the new row maximum is more than 2^8 above it (or
+            // there was none yet).  p then ranges up to 2^8 instead of 1 - harmless in f32 / bf16 - and the rescale of
+            // O below, which otherwise fires in about half of all tiles (some row of the wave sets a record), becomes
+            // rare after the first tiles.  LSE = m + log2(l) is unchanged by the choice of m.
+            const float m_cand = fmaxf(m, mx * c);
+            const float m_new = (m_cand > m + 8.f || m == -INFINITY) ? m_cand : m;
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m - m_safe);
             float rs = 0.f;
