@@ -1066,20 +1066,29 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
         __syncthreads();
     }
 
-    // dQ = scale * dQ^T^T (sink_flash_attention.py:481)
+    // dQ = scale * dQ^T^T (sink_flash_attention.py:481); 16-byte stores after one v_permlane32_swap per register (the
+    // two half-waves hold the two 8-byte halves of every 16-byte piece of a row, see the forward's store tail)
     const unsigned orow = (unsigned)qrow * (unsigned)(a.dq.sn * 2);
     typedef __attribute__((ext_vector_type(4))) E e4;
 #pragma unroll
     for (int db = 0; db < DVB; ++db)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d = 32 * db + 8 * g4 + 4 * h;
-            if (d < D) {
-                e4 pk;
+        for (int p2 = 0; p2 < 2; ++p2) {
+            if (32 * db + 16 * p2 < D) {
+                e4 pe, po;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (E)(dQt[db][4 * g4 + e] * a.scale);
+                for (int e = 0; e < 4; ++e) {
+                    pe[e] = (E)(dQt[db][8 * p2 + e] * a.scale);
+                    po[e] = (E)(dQt[db][8 * p2 + 4 + e] * a.scale);
+                }
+                const u32x2 ev = __builtin_bit_cast(u32x2, pe), od = __builtin_bit_cast(u32x2, po);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(ev[0], od[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(ev[1], od[1], false, false);
+                u32x4 w;
+                w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+                const int d = 32 * db + 16 * p2 + 8 * h;
                 const unsigned off = wave_live ? orow + (unsigned)(d * 2) : 0xFFFFFFF0u;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rdq, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rdq, off, 0, 0);
             }
         }
 }

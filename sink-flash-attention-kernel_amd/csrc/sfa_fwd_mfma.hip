@@ -318,19 +318,30 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
     if (lt == 0.f) lt = 1.f;
     const float inv = 1.f / lt;
     const unsigned orow = (unsigned)qrow * (unsigned)(a.o.sn * 2);
+    // Widened store tail: lane (row, h) holds d = 8*g4 + 4*h + {0..3} of every 32-wide block, i.e. 8-byte pieces.  One
+    // v_permlane32_swap per register hands the two half-waves each other's half of a 16-byte piece (h = 0 takes the
+    // even g4, h = 1 the odd one), so the row goes out as 16-byte stores: half the store instructions.
 #pragma unroll
     for (int db = 0; db < DVB; ++db)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d = 32 * db + 8 * g4 + 4 * h;
-            if (d < D) {
+        for (int p2 = 0; p2 < 2; ++p2) {
+            if (32 * db + 16 * p2 < D) {
                 typedef typename M::elem E;
                 typedef __attribute__((ext_vector_type(4))) E e4;
-                e4 pk;
+                e4 pe, po;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (E)(o[db][4 * g4 + e] * inv);
+                for (int e = 0; e < 4; ++e) {
+                    pe[e] = (E)(o[db][8 * p2 + e] * inv);
+                    po[e] = (E)(o[db][8 * p2 + 4 + e] * inv);
+                }
+                const u32x2 ev = __builtin_bit_cast(u32x2, pe), od = __builtin_bit_cast(u32x2, po);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(ev[0], od[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(ev[1], od[1], false, false);
+                u32x4 w;
+                w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+                const int d = 32 * db + 16 * p2 + 8 * h;
                 const unsigned off = wave_live ? orow + (unsigned)(d * 2) : 0xFFFFFFF0u;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), ro, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(w, ro, off, 0, 0);
             }
         }
     if (h == 0 && qrow < N) {
