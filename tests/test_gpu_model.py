@@ -92,3 +92,44 @@ def test_gpt_oss_training_step_gradients_kernel_vs_eager():
     for g, r in zip(got, ref):
         assert r.abs().max().item() > 0
         assert (g - r).abs().max().item() <= 2e-3 * max(1.0, r.abs().max().item()), (g - r).abs().max().item()
+
+
+def _tiny_qwen2(dtype, seed=0):
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    torch.manual_seed(seed)
+    cfg = Qwen2Config(num_hidden_layers=2, hidden_size=256, intermediate_size=512, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=512, max_position_embeddings=1024)
+    cfg._attn_implementation = "eager"
+    return Qwen2ForCausalLM(cfg).to(DEV, dtype).eval()
+
+
+def test_generate_with_sink_cache_end_to_end():
+    """model.generate() through patch_for_generation() + SinkAttentionCache (the reference's tests/test_inference.py
+    :230-292, there on a downloaded Qwen checkpoint): (1) while nothing is evicted the greedy tokens equal HF's eager
+    generation; (2) with eviction every generated token equals the argmax of ONE patched prefill pass (sink + window
+    mask) over the final sequence, i.e. the ring cache and the decode kernel implement the same attention pattern as
+    the prefill kernel."""
+    import sink_attention.generate_patch as gp
+    from sink_attention import patch_for_generation, unpatch_generation
+    model = _tiny_qwen2(torch.float32)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    ids = torch.randint(0, 512, (2, 24), device=DEV, generator=gen)
+    with torch.no_grad():
+        ref = model.generate(ids, max_new_tokens=12, do_sample=False)
+    try:
+        cache = patch_for_generation(model, num_sink=4, window_size=128)
+        _set_impl(model, "flash_attention_2")
+        with torch.no_grad():
+            out = model.generate(ids, past_key_values=cache, max_new_tokens=12, do_sample=False)
+        assert torch.equal(out, ref) and cache.seen_tokens == 24 + 11
+        # eviction: 2 sinks + a window of 16 over a 36-token sequence
+        cache = patch_for_generation(model, num_sink=2, window_size=16)
+        with torch.no_grad():
+            out2 = model.generate(ids, past_key_values=cache, max_new_tokens=12, do_sample=False)
+            assert cache.get_seq_length() == 2 + 16
+            logits = model(out2).logits           # one prefill pass of the patched model over the final sequence
+        assert gp._GENERATION_CONFIG["window_size"] == 16
+        assert torch.equal(logits[:, 23:-1].argmax(-1), out2[:, 24:])
+    finally:
+        unpatch_generation()
+        _set_impl(model, "eager")
