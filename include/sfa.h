@@ -58,6 +58,11 @@ extern "C" {
  * recompute of S and dP.  The workspace query reports the larger size; pass the SAME flags to both calls.  Ignored
  * (no extra workspace) where the MFMA backward does not apply. */
 #define SFA_FLAG_BWD_SPILL_DS 0x2u
+/* sfa_decode*: one launch instead of two.  The last KV split of a (batch, KV head) to finish folds the split partials
+ * itself (atomic arrival counters).  Contract: the caller OWNS the workspace across calls and zero-initialised its last
+ * align256((B * Hkv + 1) * 4) bytes once; the kernel leaves them zero.  Worth it at small batch, where a decode step is
+ * two ~10 us launches otherwise. */
+#define SFA_FLAG_DECODE_ONE_PASS 0x4u
 
 typedef struct sfa_tensor {
     void* ptr;         /* device pointer to element [0,0,0,0]                    */
@@ -180,6 +185,18 @@ int sfa_decode_ring_step(const sfa_tensor* q, const sfa_tensor* sink_k, const sf
                          int64_t write_pos, const sfa_tensor* k_new, const sfa_tensor* v_new, const sfa_tensor* o,
                          const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
                          void* stream);
+
+/*
+ * The same step with the cache state on the DEVICE, so that a whole generation step (all layers) can be captured
+ * into a hipGraph and replayed without host work: `state` = int32 {sink_len, window_len, write_pos}.  The call stores
+ * k_new / v_new into slot write_pos, attends over sink rows [0, sink_len) and ring slots [0, min(window_len + 1,
+ * window_size)) and then advances the state (window_len saturates at window_size, write_pos wraps).  Launch geometry
+ * does not depend on the state: workspace = sfa_decode_workspace_bytes(B, Hq, Hkv, num_sink + window_size, D, dtype).
+ */
+int sfa_decode_ring_step_dyn(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v,
+                             const sfa_tensor* window_k, const sfa_tensor* window_v, const sfa_tensor* k_new,
+                             const sfa_tensor* v_new, const sfa_tensor* o, const float* s_aux, int32_t* state,
+                             void* workspace, size_t workspace_bytes, float scale, unsigned flags, void* stream);
 
 #ifdef __cplusplus
 }

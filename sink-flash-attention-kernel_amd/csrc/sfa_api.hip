@@ -275,7 +275,8 @@ int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v
 size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype) {
     DecodePlan pl;
     if (decode_plan(B, Hq, Hkv, Nkv, D, dtype, &pl) != SFA_OK) return 0;
-    return align256((size_t)B * Hq * pl.splits * (size_t)(D + 2) * sizeof(float));
+    // split partials, then the int32 counters [B * Hkv + 1] of the one-pass mode
+    return align256((size_t)B * Hq * pl.splits * (size_t)(D + 2) * sizeof(float)) + align256((size_t)(B * Hkv + 1) * sizeof(int));
 }
 
 }  // extern "C"
@@ -286,7 +287,8 @@ namespace {
 int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
                   const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
                   size_t workspace_bytes, float scale, void* stream, const sfa_tensor* k_new = nullptr,
-                  const sfa_tensor* v_new = nullptr, int64_t new_slot = -1) {
+                  const sfa_tensor* v_new = nullptr, int64_t new_slot = -1, int* dyn_state = nullptr,
+                  unsigned flags = 0) {
     g_err[0] = 0;
     int st;
     if ((st = check_tensor(q, "q")) || (st = check_tensor(k, "k")) || (st = check_tensor(v, "v")) ||
@@ -321,7 +323,7 @@ int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
         SFA_CHECK_ARG(k_new->dtype == k2->dtype && k_new->shape[0] == k2->shape[0] && k_new->shape[1] == k2->shape[1] &&
                           k_new->shape[2] == 1 && k_new->shape[3] == k2->shape[3],
                       "k_new / v_new must be [B, H_kv, 1, D] in the ring's dtype");
-        SFA_CHECK_ARG(new_slot >= 0 && new_slot < n2, "write slot %lld outside the %lld valid ring slots",
+        SFA_CHECK_ARG(dyn_state || (new_slot >= 0 && new_slot < n2), "write slot %lld outside the %lld valid ring slots",
                       (long long)new_slot, (long long)n2);
     }
     if (q->shape[0] == 0 || q->shape[1] == 0) return SFA_OK;
@@ -343,7 +345,8 @@ int decode_common(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
         return SFA_ERR_WORKSPACE;
     }
     return decode_launch(q, k, v, n1, n2 ? k2 : nullptr, n2 ? v2 : nullptr, n2, o, s_aux, workspace, scale, pl,
-                         (hipStream_t)stream, k_new, v_new, (int)new_slot);
+                         (hipStream_t)stream, k_new, v_new, (int)new_slot, dyn_state,
+                         (flags & SFA_FLAG_DECODE_ONE_PASS) != 0);
 }
 
 }  // namespace
@@ -353,18 +356,16 @@ extern "C" {
 int sfa_decode(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* o,
                const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
                void* stream) {
-    (void)flags;
     return decode_common(q, k, v, k ? k->shape[2] : 0, nullptr, nullptr, 0, o, s_aux, workspace, workspace_bytes, scale,
-                         stream);
+                         stream, nullptr, nullptr, -1, nullptr, flags);
 }
 
 int sfa_decode_ring(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v, int64_t sink_len,
                     const sfa_tensor* window_k, const sfa_tensor* window_v, int64_t window_len, const sfa_tensor* o,
                     const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
                     void* stream) {
-    (void)flags;
     return decode_common(q, sink_k, sink_v, sink_len, window_k, window_v, window_len, o, s_aux, workspace,
-                         workspace_bytes, scale, stream);
+                         workspace_bytes, scale, stream, nullptr, nullptr, -1, nullptr, flags);
 }
 
 int sfa_decode_ring_step(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v, int64_t sink_len,
@@ -372,11 +373,23 @@ int sfa_decode_ring_step(const sfa_tensor* q, const sfa_tensor* sink_k, const sf
                          int64_t write_pos, const sfa_tensor* k_new, const sfa_tensor* v_new, const sfa_tensor* o,
                          const float* s_aux, void* workspace, size_t workspace_bytes, float scale, unsigned flags,
                          void* stream) {
-    (void)flags;
     g_err[0] = 0;
     SFA_CHECK_ARG(k_new != nullptr && v_new != nullptr, "k_new / v_new: null tensor descriptor");
     return decode_common(q, sink_k, sink_v, sink_len, window_k, window_v, window_len, o, s_aux, workspace,
-                         workspace_bytes, scale, stream, k_new, v_new, write_pos);
+                         workspace_bytes, scale, stream, k_new, v_new, write_pos, nullptr, flags);
+}
+
+int sfa_decode_ring_step_dyn(const sfa_tensor* q, const sfa_tensor* sink_k, const sfa_tensor* sink_v,
+                             const sfa_tensor* window_k, const sfa_tensor* window_v, const sfa_tensor* k_new,
+                             const sfa_tensor* v_new, const sfa_tensor* o, const float* s_aux, int32_t* state,
+                             void* workspace, size_t workspace_bytes, float scale, unsigned flags, void* stream) {
+    g_err[0] = 0;
+    SFA_CHECK_ARG(k_new != nullptr && v_new != nullptr, "k_new / v_new: null tensor descriptor");
+    SFA_CHECK_ARG(state != nullptr, "state: null device pointer");
+    SFA_CHECK_ARG(sink_k != nullptr && window_k != nullptr, "cache buffers: null tensor descriptor");
+    // launch geometry and workspace are sized for the FULL cache (every sink row, every ring slot)
+    return decode_common(q, sink_k, sink_v, sink_k->shape[2], window_k, window_v, window_k->shape[2], o, s_aux,
+                         workspace, workspace_bytes, scale, stream, k_new, v_new, 0, state, flags);
 }
 
 }  // extern "C"

@@ -56,16 +56,93 @@ __device__ __forceinline__ void cvt16B(const u32x4& raw, float (&f)[EPL]) {
 // Keys come from up to two segments (k, v: rows [0, N1); k2, v2: rows [N1, Nkv)): a contiguous cache has N1 = Nkv;
 // the sink + ring cache passes the sink buffer and the window ring (softmax is order-invariant, so the ring is read
 // in place, no linearisation copy).
+// Fold the split partials of one (b, h) and the s_aux virtual split (decode_kernel.py:205-226); `nthr` threads
+// starting at `tid` = 0 cooperate (D <= 4 * nthr).
+template <typename T>
+__device__ __forceinline__ void reduce_head(const float* __restrict__ Mp, const float* __restrict__ Lp,
+                                            const float* __restrict__ Op, const float* __restrict__ s_aux, const View& o,
+                                            int Hq, int S, int D, int b, int h, int tid, int nthr) {
+    // Latency-bound: the split statistics are fetched by all lanes at once (lane = split) and folded with wave
+    // reductions; the O rows are then accumulated with 8 independent loads in flight per thread.
+    const int64_t base = ((int64_t)b * Hq + h) * S;
+    const int wl = tid & 63;
+    const float sa = s_aux ? s_aux[h] : -INFINITY;
+    float mloc = -INFINITY;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + wl;
+        if (s < S) mloc = fmaxf(mloc, Mp[base + s]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+    const float mstar = fmaxf(mloc, sa);
+    float lloc = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + wl;
+        if (s < S) {
+            const float ms = Mp[base + s];
+            lloc += Lp[base + s] * ((ms == -INFINITY) ? 0.f : __expf(ms - mstar));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lloc += __shfl_xor(lloc, off, 64);
+    float L = lloc + ((sa == -INFINITY) ? 0.f : __expf(sa - mstar));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int s0 = 0; s0 < S; s0 += U) {
+        float w[U], x[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            const float ms = Mp[base + s];
+            w[u] = (s0 + u < S && ms != -INFINITY) ? __expf(ms - mstar) : 0.f;
+            const float* op = Op + (base + s) * D;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int d = tid + nthr * t;
+                x[u][t] = d < D ? op[d] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = fmaf(x[u][t], w[u], acc[t]);
+    }
+    L = fmaxf(L, 1e-8f);  // clamp(min=1e-8), decode_kernel.py:222
+    T* orow = reinterpret_cast<T*>(o.ptr) + (int64_t)b * o.sb + (int64_t)h * o.sh;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int d = tid + nthr * t;
+        if (d < D) orow[d] = from_f32<T>(acc[t] / L);
+    }
+}
+
+// One-pass mode (SFA_FLAG_DECODE_ONE_PASS): `cnt` = zero-initialised int32 [B * Hkv + 1] counters that the kernel
+// leaves zero.  The LAST split of a (b, KV head) to arrive (atomic counter, fences on both sides) folds the partials of
+// that head group itself, so there is no second launch; the last workgroup of the whole grid advances the device
+// state.  At B = 1 a decode step is two ~10 us launches otherwise.
+struct OnePass {
+    int* cnt;
+    const float* s_aux;
+    View o;
+};
+
 // Fused cache step (sfa_decode_ring_step): `fr.slot` >= 0 names the ring slot the token being decoded goes to.  That
 // slot's OLD content (the evicted token, or nothing yet) is never read: the key at that position comes from fr.kn /
 // fr.vn, and the first split's first lanes store it into the ring, so append + attention are one launch.
+// `dyn` (sfa_decode_ring_step_dyn): the cache state lives on the DEVICE as int32 {sink_len, window_len, write_pos}, so
+// a whole generation step can sit in a captured hipGraph: the split kernel takes its key counts and the write slot
+// from there (the grid is sized for the full cache; splits past the end produce empty partials) and the reduce kernel,
+// which the stream orders after every reader, advances the state.
 struct Fresh {
     View kn, vn;
     int slot;
+    int* dyn;       // device {sink_len, window_len before the append, write_pos} or null
+    int wsize;      // ring capacity (dyn only)
 };
 
 template <typename T, int LPK, int GT>
 __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View v, View k2, View v2, int N1, Fresh fr,
+                                                          OnePass op1,
                                                           float* __restrict__ Mp, float* __restrict__ Lp,
                                                           float* __restrict__ Op, int Hq, int Hkv, int Nkv, int D,
                                                           int kps, int S, float scale) {
@@ -85,6 +162,12 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
     const int d0 = dact ? chunk * EPL : 0;
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int g = Hq / Hkv;
+    if (fr.dyn) {
+        N1 = fr.dyn[0];
+        const int wl = fr.dyn[1] + 1 < fr.wsize ? fr.dyn[1] + 1 : fr.wsize;
+        Nkv = N1 + wl;
+        fr.slot = fr.dyn[2];
+    }
     const int k_beg = split * kps;
     const int k_end = (k_beg + kps < Nkv) ? (k_beg + kps) : Nkv;
     const int sid = wave * KPW + kg;
@@ -234,6 +317,29 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
         }
         __syncthreads();
     }
+    if (op1.cnt) {
+        __shared__ int last_flag[2];
+        __threadfence();                                   // this workgroup's partials are visible device-wide
+        if (threadIdx.x == 0) {
+            const int old = atomicAdd(&op1.cnt[b * Hkv + hk], 1);
+            last_flag[0] = old == S - 1;
+            if (old == S - 1) op1.cnt[b * Hkv + hk] = 0;   // leave the counter zero for the next call
+            const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
+            const int oldg = atomicAdd(&op1.cnt[gridDim.z * Hkv], 1);
+            last_flag[1] = oldg == total - 1;
+            if (oldg == total - 1) op1.cnt[gridDim.z * Hkv] = 0;
+        }
+        __syncthreads();
+        if (last_flag[0]) {
+            __threadfence();                               // acquire: the other splits' partials
+            for (int hh = wave; hh < g; hh += 4) reduce_head<T>(Mp, Lp, Op, op1.s_aux, op1.o, Hq, S, D, b, hk * g + hh, lane, 64);
+        }
+        if (last_flag[1] && fr.dyn && threadIdx.x == 0) {  // every workgroup has read the state: advance it
+            const int wl = fr.dyn[1], wp = fr.dyn[2];
+            fr.dyn[1] = wl + 1 < fr.wsize ? wl + 1 : fr.wsize;
+            fr.dyn[2] = wp + 1 == fr.wsize ? 0 : wp + 1;
+        }
+    }
 }
 
 // Fold the split partials and the s_aux virtual split (decode_kernel.py:205-226).
@@ -241,46 +347,29 @@ template <typename T>
 __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restrict__ Mp, const float* __restrict__ Lp,
                                                            const float* __restrict__ Op,
                                                            const float* __restrict__ s_aux, View o, int Hq, int S,
-                                                           int D) {
+                                                           int D, int* dyn, int wsize) {
     const int h = blockIdx.x, b = blockIdx.y;
-    const int64_t base = ((int64_t)b * Hq + h) * S;
-    const float sa = s_aux ? s_aux[h] : -INFINITY;
-    float mstar = sa;
-    for (int s = 0; s < S; ++s) mstar = fmaxf(mstar, Mp[base + s]);
-    float L = (sa == -INFINITY) ? 0.f : __expf(sa - mstar);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-        const float ms = Mp[base + s];
-        const float a = (ms == -INFINITY) ? 0.f : __expf(ms - mstar);
-        L += Lp[base + s] * a;
-        const float* op = Op + (base + s) * D;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int d = threadIdx.x + 128 * t;
-            if (d < D) acc[t] = fmaf(op[d], a, acc[t]);
-        }
+    if (dyn && h == 0 && b == 0 && threadIdx.x == 0) {      // every reader of the state (split kernel) has finished
+        const int wl = dyn[1], wp = dyn[2];
+        dyn[1] = wl + 1 < wsize ? wl + 1 : wsize;
+        dyn[2] = wp + 1 == wsize ? 0 : wp + 1;
     }
-    L = fmaxf(L, 1e-8f);  // clamp(min=1e-8), decode_kernel.py:222
-    T* orow = reinterpret_cast<T*>(o.ptr) + (int64_t)b * o.sb + (int64_t)h * o.sh;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int d = threadIdx.x + 128 * t;
-        if (d < D) orow[d] = from_f32<T>(acc[t] / L);
-    }
+    reduce_head<T>(Mp, Lp, Op, s_aux, o, Hq, S, D, b, h, threadIdx.x, 128);
 }
 
 template <typename T, int LPK>
-int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, View k2, View v2, int N1, Fresh fr, float* Mp,
+int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, View k2, View v2, int N1, Fresh fr,
+                 OnePass op1, float* Mp,
                  float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, int kps, int S, float scale) {
     switch (gt) {
         case 8:
-            decode_split_kernel<T, LPK, 8><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            decode_split_kernel<T, LPK, 8><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, op1, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
             break;
         case 4:
-            decode_split_kernel<T, LPK, 4><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            decode_split_kernel<T, LPK, 4><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, op1, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
             break;
         default:
-            decode_split_kernel<T, LPK, 1><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
+            decode_split_kernel<T, LPK, 1><<<grid, 256, 0, stream>>>(q, k, v, k2, v2, N1, fr, op1, Mp, Lp, Op, Hq, Hkv, Nkv, D, kps, S, scale);
             break;
     }
     return launch_status("decode_split");
@@ -288,10 +377,10 @@ int launch_split(int gt, dim3 grid, hipStream_t stream, View q, View k, View v, 
 
 template <typename T>
 int launch_split_lpk(const DecodePlan& pl, dim3 grid, hipStream_t stream, View q, View k, View v, View k2, View v2,
-                     int N1, Fresh fr, float* Mp, float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, float scale) {
+                     int N1, Fresh fr, OnePass op1, float* Mp, float* Lp, float* Op, int Hq, int Hkv, int Nkv, int D, float scale) {
 #define SFA_LPK_CASE(L)                                                                                        \
     case L:                                                                                                    \
-        return launch_split<T, L>(pl.gt, grid, stream, q, k, v, k2, v2, N1, fr, Mp, Lp, Op, Hq, Hkv, Nkv, D,   \
+        return launch_split<T, L>(pl.gt, grid, stream, q, k, v, k2, v2, N1, fr, op1, Mp, Lp, Op, Hq, Hkv, Nkv, D, \
                                   pl.keys_per_split, pl.splits, scale);
     switch (pl.lpk) {
         SFA_LPK_CASE(2)
@@ -347,37 +436,47 @@ int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int 
 int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
                   const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
                   float scale, const DecodePlan& pl, hipStream_t stream, const sfa_tensor* k_new,
-                  const sfa_tensor* v_new, int new_slot) {
+                  const sfa_tensor* v_new, int new_slot, int* dyn_state, bool one_pass) {
     const int B = (int)q->shape[0], Hq = (int)q->shape[1], D = (int)q->shape[3];
     const int Hkv = (int)k->shape[1], Nkv = (int)(n1 + n2), N1 = (int)n1;
     const View kv2 = k2 ? make_view(k2) : make_view(k);
     const View vv2 = v2 ? make_view(v2) : make_view(v);
-    Fresh fr{kv2, vv2, -1};
-    if (k_new && v_new && new_slot >= 0) fr = Fresh{make_view(k_new), make_view(v_new), new_slot};
+    const int wsize = k2 ? (int)k2->shape[2] : 0;
+    Fresh fr{kv2, vv2, -1, nullptr, wsize};
+    if (k_new && v_new && (new_slot >= 0 || dyn_state))
+        fr = Fresh{make_view(k_new), make_view(v_new), dyn_state ? 0 : new_slot, dyn_state, wsize};
     const int S = pl.splits;
     float* Mp = reinterpret_cast<float*>(workspace);
     float* Lp = Mp + (int64_t)B * Hq * S;
     float* Op = Lp + (int64_t)B * Hq * S;
+    // counters of the one-pass mode live behind the partials (256-byte aligned)
+    const size_t part_bytes = (((size_t)B * Hq * S * (size_t)(D + 2) * sizeof(float)) + 255) & ~(size_t)255;
+    one_pass = one_pass && D <= 256;      // the in-kernel fold gives a head to one wave: 64 lanes x 4 columns
+    OnePass op1{one_pass ? reinterpret_cast<int*>((char*)workspace + part_bytes) : nullptr, s_aux, make_view(o)};
     dim3 grid(S, Hkv, B);
     int st;
     if (q->dtype == SFA_DTYPE_F32)
-        st = launch_split_lpk<float>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, Mp, Lp,
+        st = launch_split_lpk<float>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, op1, Mp, Lp,
                                      Op, Hq, Hkv, Nkv, D, scale);
     else if (q->dtype == SFA_DTYPE_F16)
-        st = launch_split_lpk<f16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, Mp, Lp,
+        st = launch_split_lpk<f16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, op1, Mp, Lp,
                                      Op, Hq, Hkv, Nkv, D, scale);
     else
-        st = launch_split_lpk<bf16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, Mp, Lp,
+        st = launch_split_lpk<bf16_t>(pl, grid, stream, make_view(q), make_view(k), make_view(v), kv2, vv2, N1, fr, op1, Mp, Lp,
                                       Op, Hq, Hkv, Nkv, D, scale);
     if (st != SFA_OK) return st;
+    if (one_pass) {
+        set_path("decode_splitkv%s_1pass_lpk%d_gt%d_s%d", dyn_state ? "_ringstep_dyn" : (fr.slot >= 0 ? "_ringstep" : (k2 ? "_ring" : "")), pl.lpk, pl.gt, S);
+        return SFA_OK;
+    }
     dim3 rgrid(Hq, B);
     if (q->dtype == SFA_DTYPE_F32)
-        decode_reduce_kernel<float><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
+        decode_reduce_kernel<float><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D, dyn_state, wsize);
     else if (q->dtype == SFA_DTYPE_F16)
-        decode_reduce_kernel<f16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
+        decode_reduce_kernel<f16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D, dyn_state, wsize);
     else
-        decode_reduce_kernel<bf16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D);
-    set_path("decode_splitkv%s_lpk%d_gt%d_s%d", fr.slot >= 0 ? "_ringstep" : (k2 ? "_ring" : ""), pl.lpk, pl.gt, S);
+        decode_reduce_kernel<bf16_t><<<rgrid, 128, 0, stream>>>(Mp, Lp, Op, s_aux, make_view(o), Hq, S, D, dyn_state, wsize);
+    set_path("decode_splitkv%s_lpk%d_gt%d_s%d", dyn_state ? "_ringstep_dyn" : (fr.slot >= 0 ? "_ringstep" : (k2 ? "_ring" : "")), pl.lpk, pl.gt, S);
     return launch_status("decode_reduce");
 }
 

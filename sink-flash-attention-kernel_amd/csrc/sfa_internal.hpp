@@ -43,6 +43,7 @@ int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int 
 int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,
                   const sfa_tensor* v2, int64_t n2, const sfa_tensor* o, const float* s_aux, void* workspace,
                   float scale, const DecodePlan& plan, hipStream_t stream, const sfa_tensor* k_new = nullptr,
-                  const sfa_tensor* v_new = nullptr, int new_slot = -1);
+                  const sfa_tensor* v_new = nullptr, int new_slot = -1, int* dyn_state = nullptr,
+                  bool one_pass = false);
 
 }  // namespace sfa

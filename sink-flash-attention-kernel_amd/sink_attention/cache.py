@@ -153,7 +153,8 @@ class SinkCacheLayer(_HFLayer if _HAS_HF else object):
                                                       N.SFA_DTYPE[q.dtype])
             st = dict(key=key, lib=lib, scale=1.0 / math.sqrt(D),
                       descs=[N.desc(t) for t in (self.sink_k, self.sink_v, self.window_k, self.window_v)],
-                      ws=torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8))
+                      # owned across calls and zeroed once: the one-pass decode keeps its arrival counters there
+                      ws=torch.zeros((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8))
             self._step_state = st
         N.require_gpu(q, k_new, v_new, s_aux)
         if k_new.dtype != q.dtype or v_new.dtype != q.dtype or k_new.shape != v_new.shape:
@@ -166,9 +167,71 @@ class SinkCacheLayer(_HFLayer if _HAS_HF else object):
             rc = st["lib"].sfa_decode_ring_step(N.desc(q), sk, sv, self.sink_len, wk, wv, new_len, pos, N.desc(k_new),
                                                 N.desc(v_new), N.desc(out),
                                                 s_aux_f.data_ptr() if s_aux_f is not None else None,
-                                                st["ws"].data_ptr(), st["ws"].numel(), st["scale"], 0,
-                                                N.stream_ptr(q.device))
+                                                st["ws"].data_ptr(), st["ws"].numel(), st["scale"],
+                                                self._decode_flags(N), N.stream_ptr(q.device))
         N.check(rc, "sfa_decode_ring_step")
+        return out
+
+    one_pass = False     # opt-in: SFA_FLAG_DECODE_ONE_PASS (last-arriver fold inside the split kernel, one launch)
+
+    def _decode_flags(self, N) -> int:
+        # Measured on MI355X at B=1: 18 vs 21 us per step at W=1024 but 28-38 vs 22-28 us at W=4096 - the agent-scope
+        # fences around the arrival counter write back / invalidate the per-XCD L2s - so two launches stay the default.
+        return N.FLAG_DECODE_ONE_PASS if self.one_pass else 0
+
+    # ------------------------------------------------ device-resident state (hipGraph capture)
+    def enable_device_state(self) -> torch.Tensor:
+        """Move the ring bookkeeping {sink_len, window_len, write_pos} to a device int32 tensor so that
+        ``decode_step_dyn`` needs no host-side integers: a whole generation step can then be captured with
+        ``torch.cuda.graph`` and replayed (the kernels read and advance the state themselves).  Call after prefill."""
+        assert self.is_initialized and self.prefilled and self.window_size > 0, "prefill the cache first"
+        self._dev_state = torch.tensor([self.sink_len, self.window_len, self.write_pos], dtype=torch.int32,
+                                       device=self.window_k.device)
+        return self._dev_state
+
+    def pull_state(self) -> None:
+        """Refresh the host-side counters from the device state (one small device-to-host copy)."""
+        st = getattr(self, "_dev_state", None)
+        if st is not None:
+            sl, wl, wp = st.tolist()
+            self.seen_tokens += (wl - self.window_len) if wl < self.window_size or self.window_len < self.window_size \
+                else ((wp - self.write_pos) % self.window_size)
+            self.sink_len, self.window_len, self.write_pos = sl, wl, wp
+
+    def decode_step_dyn(self, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor,
+                        s_aux: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``decode_step`` with the state on the device (``sfa_decode_ring_step_dyn``): capturable into a hipGraph.
+        ``out`` (optional, [B,H_q,1,D]) lets the caller keep a static output buffer across replays."""
+        import math
+        from . import _native as N
+        st = getattr(self, "_dev_state", None)
+        assert st is not None, "call enable_device_state() first"
+        ss = getattr(self, "_step_state", None)
+        key = (self.sink_k.data_ptr(), self.window_k.data_ptr(), q.shape, q.dtype)
+        if ss is None or ss["key"] != key:
+            B, H_q, _one, D = q.shape
+            lib = N.lib()
+            ws_bytes = lib.sfa_decode_workspace_bytes(B, H_q, self.sink_k.shape[1], self.num_sink + self.window_size, D,
+                                                      N.SFA_DTYPE[q.dtype])
+            ss = dict(key=key, lib=lib, scale=1.0 / math.sqrt(D),
+                      descs=[N.desc(t) for t in (self.sink_k, self.sink_v, self.window_k, self.window_v)],
+                      # owned across calls and zeroed once: the one-pass decode keeps its arrival counters there
+                      ws=torch.zeros((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8))
+            self._step_state = ss
+        N.require_gpu(q, k_new, v_new, s_aux)
+        if k_new.dtype != q.dtype or v_new.dtype != q.dtype or q.dtype != self.window_k.dtype:
+            raise TypeError("q, k_new, v_new and the cache buffers must share one dtype")
+        q, k_new, v_new = N.unit_inner(q.detach()), N.unit_inner(k_new.detach()), N.unit_inner(v_new.detach())
+        s_aux_f = s_aux.detach().contiguous().float() if s_aux is not None else None
+        if out is None:
+            out = torch.empty(q.shape, device=q.device, dtype=q.dtype)
+        sk, sv, wk, wv = ss["descs"]
+        with torch.cuda.device(q.device):
+            rc = ss["lib"].sfa_decode_ring_step_dyn(N.desc(q), sk, sv, wk, wv, N.desc(k_new), N.desc(v_new), N.desc(out),
+                                                    s_aux_f.data_ptr() if s_aux_f is not None else None, st.data_ptr(),
+                                                    ss["ws"].data_ptr(), ss["ws"].numel(), ss["scale"],
+                                                    self._decode_flags(N), N.stream_ptr(q.device))
+        N.check(rc, "sfa_decode_ring_step_dyn")
         return out
 
     # ------------------------------------------------------- HF layer surface

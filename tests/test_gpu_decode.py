@@ -232,3 +232,81 @@ def test_fused_cache_step_matches_append_then_decode(dtype, Hq, Hkv, D, ns, W, p
     kc, vc = a.get_kv()
     o_ref = O.decode_dense(q.cpu(), kc.cpu(), vc.cpu(), sa.cpu())
     assert maxdiff(out, o_ref) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+def test_decode_step_in_a_hip_graph_with_device_state():
+    """One generation step of a 3-layer cache captured ONCE with torch.cuda.graph and replayed: the kernels take
+    {sink_len, window_len, write_pos} from device memory and advance them, so no host integer changes between replays.
+    Every replay must equal the eager fused step on a twin cache, across ring wrap-around."""
+    from sink_attention.cache import SinkCacheLayer
+    g = torch.Generator().manual_seed(97)
+    B, Hq, Hkv, D, ns, W, L = 2, 8, 2, 128, 4, 24, 3
+    dt = torch.float16
+    graph_layers = [SinkCacheLayer(ns, W) for _ in range(L)]
+    eager_layers = [SinkCacheLayer(ns, W) for _ in range(L)]
+    for a, b in zip(graph_layers, eager_layers):
+        kp, vp = rand((B, Hkv, 10, D), g, dt).to(DEV), rand((B, Hkv, 10, D), g, dt).to(DEV)
+        a.update(kp, vp)
+        b.update(kp, vp)
+        a.enable_device_state()
+    sa = rand((Hq,), g, torch.float32, 0.5).to(DEV)
+    # static buffers of the captured step
+    qs = [torch.zeros(B, Hq, 1, D, device=DEV, dtype=dt) for _ in range(L)]
+    ks = [torch.zeros(B, Hkv, 1, D, device=DEV, dtype=dt) for _ in range(L)]
+    vs = [torch.zeros(B, Hkv, 1, D, device=DEV, dtype=dt) for _ in range(L)]
+    outs = [torch.zeros(B, Hq, 1, D, device=DEV, dtype=dt) for _ in range(L)]
+
+    def step():
+        for i, layer in enumerate(graph_layers):
+            layer.decode_step_dyn(qs[i], ks[i], vs[i], s_aux=sa, out=outs[i])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):           # warm-up outside the graph (advances the device state by one token)
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    for i, b in enumerate(eager_layers):    # twin takes the same (all-zero) token
+        b.decode_step(qs[i], ks[i], vs[i], s_aux=sa)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for i, b in enumerate(eager_layers):    # the capture itself does not execute: nothing to mirror; replay now
+        pass
+    for t in range(W + 6):
+        for i in range(L):
+            qs[i].copy_(rand((B, Hq, 1, D), g, dt))
+            ks[i].copy_(rand((B, Hkv, 1, D), g, dt))
+            vs[i].copy_(rand((B, Hkv, 1, D), g, dt))
+        graph.replay()
+        torch.cuda.synchronize()
+        for i, b in enumerate(eager_layers):
+            ref = b.decode_step(qs[i], ks[i], vs[i], s_aux=sa)
+            assert torch.equal(outs[i], ref), (t, i)
+    for a, b in zip(graph_layers, eager_layers):
+        a.pull_state()
+        assert (a.sink_len, a.window_len, a.write_pos) == (b.sink_len, b.window_len, b.write_pos)
+        assert torch.equal(a.window_k, b.window_k) and torch.equal(a.window_v, b.window_v)
+
+
+def test_one_pass_decode_matches_two_launches():
+    """SFA_FLAG_DECODE_ONE_PASS (the last split to arrive folds the partials inside the split kernel) against the
+    default two-launch decode, through the cache's fused step, over several steps (the arrival counters must be left
+    zero by every call)."""
+    from sink_attention import _native
+    from sink_attention.cache import SinkCacheLayer
+    g = torch.Generator().manual_seed(101)
+    B, Hq, Hkv, D, ns, W = 2, 16, 2, 128, 4, 600
+    a, b = SinkCacheLayer(ns, W), SinkCacheLayer(ns, W)
+    a.one_pass = True
+    kp, vp = rand((B, Hkv, 700, D), g, torch.bfloat16).to(DEV), rand((B, Hkv, 700, D), g, torch.bfloat16).to(DEV)
+    a.update(kp, vp)
+    b.update(kp, vp)
+    sa = rand((Hq,), g, torch.float32, 0.5).to(DEV)
+    for step in range(6):
+        q = rand((B, Hq, 1, D), g, torch.bfloat16).to(DEV)
+        kn, vn = rand((B, Hkv, 1, D), g, torch.bfloat16).to(DEV), rand((B, Hkv, 1, D), g, torch.bfloat16).to(DEV)
+        o1 = a.decode_step(q, kn, vn, s_aux=sa)
+        assert "1pass" in _native.last_path()
+        o2 = b.decode_step(q, kn, vn, s_aux=sa)
+        assert "1pass" not in _native.last_path()
+        assert torch.equal(o1, o2), step
