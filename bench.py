@@ -175,7 +175,7 @@ def main():
     do = torch.randn(B, Hq, N, D, device=dev, dtype=torch.bfloat16)
 
     lib = _native.lib()
-    stage = HipEvents(4)
+    stages = [HipEvents(4) for _ in range(args.steps)]     # one set per timed step: per-kernel AVERAGES over the region
     fwd_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     paths = {}
 
@@ -199,16 +199,12 @@ def main():
         step()
     barrier()
     paths["bwd"] = _native.last_path()
-    stage_ms = {"pre": [], "dkdv": [], "dq": []}
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = i == args.steps - 1
-        if last:      # stage events are armed for the final timed step only (one extra hipEventRecord x4)
-            lib.sfa_debug_set_stage_events(stage.ev, 4)
+        # the library records 4 events of set i on its launch stream during this step's backward (a few us of host work)
+        lib.sfa_debug_set_stage_events(stages[i].ev, 4)
         step(i)
-        if last:
-            torch.cuda.synchronize()
-            lib.sfa_debug_set_stage_events(None, 0)
+    lib.sfa_debug_set_stage_events(None, 0)
     barrier()
     dt = reduce_max_seconds(time.perf_counter() - t0, dev, world)
 
@@ -220,7 +216,8 @@ def main():
     if rank == 0:
         fwd_ms = sorted(s.elapsed_time(e) for s, e in fwd_ev)
         fwd_avg = sum(fwd_ms) / len(fwd_ms)
-        pre, dkdv, dq = stage.elapsed(0, 1), stage.elapsed(1, 2), stage.elapsed(2, 3)
+        avg = lambda a, b: sum(st.elapsed(a, b) for st in stages) / len(stages)
+        pre, dkdv, dq = avg(0, 1), avg(1, 2), avg(2, 3)
         # algorithmic FLOPs per kernel: fwd 4, dK/dV kernel 4 (dV, dK) + its share ... -> use the 5-product split:
         # S and dP recomputations are not algorithmic work; dK/dV kernel owns dV+dK (4*D*pairs) plus S,dP (4) = 8,
         # dQ kernel owns dQ (2*D*pairs).  The two backward kernels together carry the 10*D*pairs of the backward.
