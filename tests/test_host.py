@@ -171,3 +171,16 @@ def test_spill_workspace_query_and_varlen_support_need_no_gpu():
         lib.sfa_bwd_workspace_bytes(4, 32, 8, 8192, 128, 0, 4, 4096, 0)
     assert lib.sfa_varlen_supported(2, 128) == 1 and lib.sfa_varlen_supported(1, 64) == 1
     assert lib.sfa_varlen_supported(0, 128) == 0 and lib.sfa_varlen_supported(2, 256) == 0
+
+
+def test_header_is_plain_c():
+    """include/sfa.h must compile as C99 (it is the FFI surface: no C++ / HIP / torch types)."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write('#include "sfa.h"\nint main(void) { sfa_tensor t; t.dtype = SFA_DTYPE_BF16; return t.dtype == SFA_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                        "-fsyntax-only", f.name], capture_output=True, text=True)
+    os.unlink(f.name)
+    assert r.returncode == 0, r.stderr
