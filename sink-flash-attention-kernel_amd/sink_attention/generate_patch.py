@@ -13,10 +13,7 @@ Differences: the [B,N,H,D] activations go to the kernels as strided views and th
 [B,N,H,D] memory (no transpose+contiguous copies, :113-116,:134); patching twice keeps the TRUE original (the reference
 would save its own replacement as "original" and recurse on fallback).
 """
-from typing import Optional
-
-import torch
-
+from . import _hf_args as _hf
 from .cache import SinkAttentionCache
 from .decode_kernel import sink_decode_attention
 from .sink_flash_attention import _sink_flash_attention_ex
@@ -26,53 +23,23 @@ _original_flash_attention_forward = None
 _GENERATION_CONFIG = {"num_sink": 4, "window_size": 4096, "enabled": False, "honor_s_aux": False}
 
 
-def _is_packed(position_ids) -> bool:
-    if position_ids is None or position_ids.dim() < 2 or position_ids.size(1) <= 1:
-        return False
-    return bool((position_ids[:, 1:] < position_ids[:, :-1]).any().item())
-
-
-def _generation_flash_attention_forward(
-    query_states: torch.Tensor,
-    key_states: torch.Tensor,
-    value_states: torch.Tensor,
-    attention_mask: Optional[torch.Tensor],
-    query_length: int,
-    is_causal: bool = True,
-    dropout: float = 0.0,
-    position_ids: Optional[torch.Tensor] = None,
-    softmax_scale: Optional[float] = None,
-    sliding_window: Optional[int] = None,
-    use_top_left_mask: bool = False,
-    softcap: Optional[float] = None,
-    deterministic: Optional[bool] = None,
-    cu_seq_lens_q: Optional[torch.LongTensor] = None,
-    cu_seq_lens_k: Optional[torch.LongTensor] = None,
-    max_length_q: Optional[int] = None,
-    max_length_k: Optional[int] = None,
-    target_dtype: Optional[torch.dtype] = None,
-    implementation: Optional[str] = None,
-    **kwargs,
-):
+def _generation_flash_attention_forward(query_states, key_states, value_states, attention_mask, query_length,
+                                        *args, **kwargs):
     """Replacement for transformers' ``_flash_attention_forward`` during generation; tensors are [B, N, H, D]."""
-    varlen = all(x is not None for x in (cu_seq_lens_q, cu_seq_lens_k, max_length_q, max_length_k))
-    packed = position_ids is not None and query_states.size(0) > 0 and _is_packed(position_ids)
-    if varlen or packed or not is_causal:
-        return _original_flash_attention_forward(
-            query_states, key_states, value_states, attention_mask, query_length,
-            is_causal=is_causal, dropout=dropout, position_ids=position_ids, softmax_scale=softmax_scale,
-            sliding_window=sliding_window, use_top_left_mask=use_top_left_mask, softcap=softcap,
-            deterministic=deterministic, cu_seq_lens_q=cu_seq_lens_q, cu_seq_lens_k=cu_seq_lens_k,
-            max_length_q=max_length_q, max_length_k=max_length_k, target_dtype=target_dtype,
-            implementation=implementation, **kwargs)
+    kw = _hf.bind(args, kwargs)
+    position_ids = kw.get("position_ids")
+    packed = position_ids is not None and query_states.size(0) > 0 and _hf.is_packed(position_ids)
+    if _hf.wants_varlen(kw) or packed or not kw.get("is_causal", True):
+        return _original_flash_attention_forward(query_states, key_states, value_states, attention_mask, query_length,
+                                                 **kw)
 
-    s_aux = kwargs.get("s_aux") if _GENERATION_CONFIG["honor_s_aux"] else None
+    s_aux = kw.get("s_aux") if _GENERATION_CONFIG["honor_s_aux"] else None
     if s_aux is not None and s_aux.shape[0] != query_states.shape[2]:
         s_aux = None
     q = query_states.transpose(1, 2)         # [B, H, N, D] strided views, no copies
     k = key_states.transpose(1, 2)
     v = value_states.transpose(1, 2)
-    if q.shape[2] > 1:                        # prefill: N_q == N_kv, the kernel masks (sink + window)
+    if q.shape[2] > 1:                        # prefill (N_q <= N_kv): the kernel masks (sink + window)
         out = _sink_flash_attention_ex(q, k, v, _GENERATION_CONFIG["num_sink"], _GENERATION_CONFIG["window_size"],
                                        s_aux=s_aux, out_bnhd=True)
         return out.transpose(1, 2)            # already contiguous [B, N, H, D]

@@ -14,10 +14,10 @@ transpose+contiguous copies per call, :119-126,:164-177); ``unpatch_verl`` reset
 original so a later re-patch works (the reference leaves it set, making re-patching a no-op).
 """
 import os
-from typing import Optional
 
 import torch
 
+from . import _hf_args as _hf
 from .decode_kernel import sink_decode_attention
 from .sink_flash_attention import _sink_flash_attention_ex
 
@@ -50,44 +50,25 @@ def _local_s_aux(s_aux, H_q):
 
 
 def _is_packed(position_ids) -> bool:
-    """True when position_ids [B, N] restart inside a row (several sequences packed in one)."""
-    if position_ids is None or position_ids.dim() < 2 or position_ids.size(1) <= 1:
-        return False
-    return bool((position_ids[:, 1:] < position_ids[:, :-1]).any().item())
+    return _hf.is_packed(position_ids)
 
 
-def _sink_flash_attention_forward(
-    query_states: torch.Tensor,
-    key_states: torch.Tensor,
-    value_states: torch.Tensor,
-    attention_mask: Optional[torch.Tensor],
-    query_length: int,
-    is_causal: bool = True,
-    dropout: float = 0.0,
-    position_ids: Optional[torch.Tensor] = None,
-    softmax_scale: Optional[float] = None,
-    sliding_window: Optional[int] = None,
-    use_top_left_mask: bool = False,
-    softcap: Optional[float] = None,
-    deterministic: Optional[bool] = None,
-    cu_seq_lens_q: Optional[torch.LongTensor] = None,
-    cu_seq_lens_k: Optional[torch.LongTensor] = None,
-    max_length_q: Optional[int] = None,
-    max_length_k: Optional[int] = None,
-    target_dtype: Optional[torch.dtype] = None,
-    implementation: Optional[str] = None,
-    **kwargs,
-):
+def _sink_flash_attention_forward(query_states, key_states, value_states, attention_mask, query_length,
+                                  *args, **kwargs):
     """Replacement for transformers' ``_flash_attention_forward``; tensors are [B, N, H, D]."""
-    s_aux = kwargs.pop("s_aux", None)
+    kw = _hf.bind(args, kwargs)
+    s_aux = kw.pop("s_aux", None)
+    is_causal, sliding_window = kw.get("is_causal", True), kw.get("sliding_window")
+    position_ids = kw.get("position_ids")
+    varlen = _hf.wants_varlen(kw)
+    packed = position_ids is not None and query_states.size(0) > 0 and _hf.is_packed(position_ids)
+    plain = is_causal and attention_mask is None and kw.get("softcap") is None
 
-    varlen = all(x is not None for x in (cu_seq_lens_q, cu_seq_lens_k, max_length_q, max_length_k))
-    packed = position_ids is not None and query_states.size(0) > 0 and _is_packed(position_ids)
-    if (ENABLE_VARLEN and (varlen or packed) and is_causal and attention_mask is None and softcap is None
+    if (ENABLE_VARLEN and (varlen or packed) and plain
             and query_states.shape[0] == 1 and query_states.shape[1] == key_states.shape[1]):
         from .varlen import seq_bounds_from_position_ids, sink_flash_attention_varlen
         if varlen:     # device offsets + the longest length: no host synchronisation
-            cu, max_len = cu_seq_lens_q, int(max_length_q)
+            cu, max_len = kw["cu_seq_lens_q"], int(kw["max_length_q"])
         else:
             cu, max_len = seq_bounds_from_position_ids(position_ids[0] if position_ids.dim() > 1 else position_ids), None
         T = query_states.shape[1]
@@ -96,16 +77,11 @@ def _sink_flash_attention_forward(
                                           window_size=sliding_window if sliding_window is not None else T,
                                           s_aux=_local_s_aux(s_aux, query_states.shape[2]), max_seqlen=max_len)
         return out.transpose(1, 2).contiguous()
-    if varlen or packed or not is_causal or attention_mask is not None or softcap is not None:
+    if varlen or packed or not plain:
         if s_aux is not None:
-            kwargs["s_aux"] = s_aux
-        return _original_flash_attention_forward(
-            query_states, key_states, value_states, attention_mask, query_length,
-            is_causal=is_causal, dropout=dropout, position_ids=position_ids, softmax_scale=softmax_scale,
-            sliding_window=sliding_window, use_top_left_mask=use_top_left_mask, softcap=softcap,
-            deterministic=deterministic, cu_seq_lens_q=cu_seq_lens_q, cu_seq_lens_k=cu_seq_lens_k,
-            max_length_q=max_length_q, max_length_k=max_length_k, target_dtype=target_dtype,
-            implementation=implementation, **kwargs)
+            kw["s_aux"] = s_aux
+        return _original_flash_attention_forward(query_states, key_states, value_states, attention_mask, query_length,
+                                                 **kw)
 
     N_q, H_q = query_states.shape[1], query_states.shape[2]
     N_kv = key_states.shape[1]
@@ -114,9 +90,11 @@ def _sink_flash_attention_forward(
     k = key_states.transpose(1, 2)
     v = value_states.transpose(1, 2)
 
-    if N_q != N_kv:                         # decode step against a KV cache
+    if N_q == 1 and N_kv != 1:              # decode step against a KV cache
         out = sink_decode_attention(q, k, v, s_aux=s_aux_local)       # [B, H, 1, D]
         return out.transpose(1, 2).contiguous()
+    # N_q < N_kv with N_q > 1 (chunked prefill against a cache; the reference would hand it to the decode kernel and
+    # fail its N_q == 1 assert): the prefill kernels take the queries as the last N_q key positions
 
     window_size = sliding_window if sliding_window is not None else N_q
     out = _sink_flash_attention_ex(q, k, v, 0, window_size, s_aux=s_aux_local, out_bnhd=True)
