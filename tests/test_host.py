@@ -184,3 +184,21 @@ def test_header_is_plain_c():
                         "-fsyntax-only", f.name], capture_output=True, text=True)
     os.unlink(f.name)
     assert r.returncode == 0, r.stderr
+
+
+def test_hf_option_binding():
+    from sink_attention import _hf_args as H
+    kw = H.bind((False, 0.1), {"sliding_window": 7, "s_aux": "x"})
+    assert kw == {"is_causal": False, "dropout": 0.1, "sliding_window": 7, "s_aux": "x"}
+    with pytest.raises(TypeError):
+        H.bind((True,), {"is_causal": False})
+    with pytest.raises(TypeError):
+        H.bind(tuple(range(len(H.OPTIONAL_ORDER) + 1)), {})
+    assert H.wants_varlen({"cu_seq_lens_q": 1, "cu_seq_lens_k": 1, "max_length_q": 1, "max_length_k": 1})
+    assert not H.wants_varlen({"cu_seq_lens_q": 1})
+    # the order is the one of the installed transformers
+    import inspect
+    import transformers.modeling_flash_attention_utils as fa
+    params = list(inspect.signature(fa._flash_attention_forward).parameters)
+    tail = [p for p in params[5:] if p in H.OPTIONAL_ORDER]
+    assert tail == [p for p in H.OPTIONAL_ORDER if p in tail]
