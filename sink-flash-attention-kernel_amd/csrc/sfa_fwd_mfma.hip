@@ -268,15 +268,25 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
             const float m_new = (m_cand > m + 8.f || m == -INFINITY) ? m_cand : m;
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m - m_safe);
-            float rs = 0.f;
+            // packed f32 math (v_pk_fma_f32 / v_pk_add_f32: two elements per issue slot) for the exponent argument and
+            // the row sum; the kernel issues ~8 VALU instructions per MFMA, so VALU issue slots matter as much as MFMAs
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 c2 = {c, c}, nm2 = {-m_safe, -m_safe};
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kh][i], c, -m_safe));
-                    s[kh][i] = p;
-                    rs += p;
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 sv = {s[kh][i], s[kh][i + 1]};
+                    const f32x2 x = __builtin_elementwise_fma(sv, c2, nm2);
+                    f32x2 p;
+                    p[0] = __builtin_amdgcn_exp2f(x[0]);
+                    p[1] = __builtin_amdgcn_exp2f(x[1]);
+                    s[kh][i] = p[0];
+                    s[kh][i + 1] = p[1];
+                    rs2 += p;
                 }
+            const float rs = rs2[0] + rs2[1];
             l = fmaf(l, alpha, rs);
             m = m_new;
             if (!__all(alpha == 1.f)) {
