@@ -1030,10 +1030,19 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
                 }
                 frag pS[2];
                 if (full) {
+                    // packed f32 math (two elements per VALU issue slot) around the 16 exp2
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 c2 = {c, c}, nl2 = {-lse2, -lse2}, nd2 = {-dlt, -dlt};
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
-                        pS[i >> 3][i & 7] = (E)(p * (dP[i] - dlt));
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 sv = {S[i], S[i + 1]}, dv = {dP[i], dP[i + 1]};
+                        const f32x2 x = __builtin_elementwise_fma(sv, c2, nl2);
+                        f32x2 p;
+                        p[0] = __builtin_amdgcn_exp2f(x[0]);
+                        p[1] = __builtin_amdgcn_exp2f(x[1]);
+                        const f32x2 ds = p * (dv + nd2);
+                        pS[i >> 3][i & 7] = (E)ds[0];
+                        pS[i >> 3][(i & 7) + 1] = (E)ds[1];
                     }
                 } else {
                     int qm = qrow + P;
