@@ -1419,11 +1419,8 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
             ds_prefix_kernel<<<dim3(1), dim3(256), 0, stream>>>(const_cast<int*>(a.ds_prefix), a.n_kblocks, a.N,
                                                                 a.num_sink, a.window);
             auto kern = bwd_dkdv_mfma_kernel_ws<T, D, true>;
-            static bool done = false;
-            if (!done) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                done = true;
-            }
+            static unsigned long long done = 0;
+            ensure_dynamic_lds((const void*)kern, lds, &done);
             kern<<<dim3(nblk), dim3(512), lds, stream>>>(a);
             int st = launch_status("bwd_dkdv_mfma_ws_spill");
             if (st) return st;
@@ -1436,20 +1433,14 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
             if (gr == 4) {
                 constexpr int glds = 2 * 64 * ROWB + 8 * 4 * 4096;
                 auto gk = bwd_dq_gemm_kernel<T, D, 4, 2>;
-                static bool gdone = false;
-                if (!gdone) {
-                    (void)hipFuncSetAttribute((const void*)gk, hipFuncAttributeMaxDynamicSharedMemorySize, glds);
-                    gdone = true;
-                }
+                static unsigned long long gdone = 0;
+                ensure_dynamic_lds((const void*)gk, glds, &gdone);
                 gk<<<dim3((unsigned)gblk), dim3(576), glds, stream>>>(a);
             } else {
                 constexpr int glds = 3 * 64 * ROWB + 8 * 3 * 4096;
                 auto gk = bwd_dq_gemm_kernel<T, D, 3, 3>;
-                static bool gdone = false;
-                if (!gdone) {
-                    (void)hipFuncSetAttribute((const void*)gk, hipFuncAttributeMaxDynamicSharedMemorySize, glds);
-                    gdone = true;
-                }
+                static unsigned long long gdone = 0;
+                ensure_dynamic_lds((const void*)gk, glds, &gdone);
                 gk<<<dim3((unsigned)gblk), dim3(576), glds, stream>>>(a);
             }
             const int gnw = gr;
@@ -1457,22 +1448,16 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
             return launch_status("bwd_dq_gemm");
         }
         auto kern = bwd_dkdv_mfma_kernel_ws<T, D, false>;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static unsigned long long done = 0;
+        ensure_dynamic_lds((const void*)kern, lds, &done);
         kern<<<dim3(nblk), dim3(512), lds, stream>>>(a);
         int st = launch_status("bwd_dkdv_mfma_ws");
         if (st) return st;
     } else {
         constexpr int lds = 2 * (2 * 64 * ROWB + 512);
         auto kern = bwd_dkdv_mfma_kernel<T, D>;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static unsigned long long done = 0;
+        ensure_dynamic_lds((const void*)kern, lds, &done);
         const int nblk = a.n_kblocks * a.Hkv * B;
         kern<<<dim3(nblk), dim3(256), lds, stream>>>(a);
         int st = launch_status("bwd_dkdv_mfma");
@@ -1496,22 +1481,16 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t stream) {
         a4.n_qtiles = (int)cdiv64(a.N, 32 * a4.rb);
         a4.hgroups = g / a4.hpw;
         auto kern = bwd_dq_mfma_kernel<T, D, NW>;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static unsigned long long done = 0;
+        ensure_dynamic_lds((const void*)kern, lds, &done);
         const int64_t nblk = (int64_t)a4.n_qtiles * a4.hgroups * a.Hkv * B;
         kern<<<dim3((unsigned)nblk), dim3(NW * 64), lds, stream>>>(a4);
     } else {
         constexpr int NW = 8;
         constexpr int lds = 2 * 2 * 64 * ROWB;
         auto kern = bwd_dq_mfma_kernel<T, D, NW>;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static unsigned long long done = 0;
+        ensure_dynamic_lds((const void*)kern, lds, &done);
         const int nblk = a.n_qtiles * a.hgroups * a.Hkv * B;
         kern<<<dim3(nblk), dim3(NW * 64), lds, stream>>>(a);
     }

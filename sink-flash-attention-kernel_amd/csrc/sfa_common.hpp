@@ -26,6 +26,19 @@ void record_stage(int i, hipStream_t stream);  // no-op unless sfa_debug_set_sta
         }                                    \
     } while (0)
 
+// Dynamic LDS above the default limit needs hipFuncAttributeMaxDynamicSharedMemorySize, and function attributes are
+// per DEVICE: a process that drives several GPUs (HF device_map="auto", pipeline stages) launches the same kernel on
+// all of them.  `flags` is a per-call-site bitmask of the devices already prepared.
+inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* flags) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(*flags & bit)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        *flags |= bit;
+    }
+}
+
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -365,11 +365,8 @@ int launch(const FwdArgs& a, int nblk, hipStream_t stream) {
     constexpr int ROWB = (D <= 64) ? 128 : 256;
     constexpr int lds = 2 * 2 * 64 * ROWB;
     auto kern = fwd_mfma_kernel<T, D, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;
+    ensure_dynamic_lds((const void*)kern, lds, &attr_done);
     kern<<<dim3(nblk), dim3(NW * 64), lds, stream>>>(a);
     set_path("fwd_mfma_%s_d%d_nw%d_hpw%d", sizeof(T) == 2 && DT<T>::id == SFA_DTYPE_BF16 ? "bf16" : "f16", D, NW,
              a.hpw);
