@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
     constexpr int EPL = 16 / sizeof(T);
     constexpr int KPW = 64 / LPK;
     constexpr int NSTREAM = 4 * KPW;
-    constexpr int U = (GT <= 1) ? 8 : 4;
+    constexpr int U = (GT <= 4) ? 8 : 4;
     constexpr int DP = LPK * EPL;  // padded head dim covered by a lane group
 
     __shared__ float sm[4][GT];
@@ -414,7 +414,7 @@ int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int 
     while (lpk < chunks) lpk <<= 1;
     const int64_t g = Hq / Hkv;
     const int gt = (g % 8 == 0) ? 8 : (g % 4 == 0) ? 4 : 1;
-    const int U = gt <= 1 ? 8 : 4;
+    const int U = gt <= 4 ? 8 : 4;
     const int iter_keys = 4 * (64 / lpk) * U;
     const int64_t target_wgs = 2048;
     const int64_t base = B * Hkv > 0 ? B * Hkv : 1;
