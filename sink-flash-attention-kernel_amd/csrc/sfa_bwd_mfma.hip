@@ -1047,12 +1047,32 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
                 } else {
                     int qm = qrow + P;
                     asm volatile("; edge tile" : "+v"(qm) : : "memory");     // side effect: the branch cannot be speculated / if-converted
+                    // as in the forward: most edge tiles need only the causal OR only the window test, one compare
+                    // of the element's constant offset against a per-lane threshold
+                    // (head dims below 128 only: at D = 128 the extra paths push the kernel over its register budget)
+                    const bool no_sink = D < 128 && k0 >= ns;
+                    if (no_sink && k0 >= pw_hi - W + 1) {
+                        const int t = qm - k0 - 32 * kh - 4 * h;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool valid = (key <= qm) && (key < ns || key + W > qm);
-                        const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
-                        pS[i >> 3][i & 7] = (E)(valid ? p * (dP[i] - dlt) : 0.f);
+                        for (int i = 0; i < 16; ++i) {
+                            const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
+                            pS[i >> 3][i & 7] = (E)(((i & 3) + 8 * (i >> 2) <= t) ? p * (dP[i] - dlt) : 0.f);
+                        }
+                    } else if (no_sink && k0 + 63 <= pw0) {
+                        const int t = qm - W - k0 - 32 * kh - 4 * h;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
+                            pS[i >> 3][i & 7] = (E)(((i & 3) + 8 * (i >> 2) > t) ? p * (dP[i] - dlt) : 0.f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            const bool valid = (key <= qm) && (key < ns || key + W > qm);
+                            const float p = __builtin_amdgcn_exp2f(fmaf(S[i], c, -lse2));
+                            pS[i >> 3][i & 7] = (E)(valid ? p * (dP[i] - dlt) : 0.f);
+                        }
                     }
                 }
 #pragma unroll

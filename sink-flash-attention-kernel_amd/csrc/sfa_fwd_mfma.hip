@@ -245,14 +245,34 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
             if (!full) {
                 int qm = qrow + P;
                 asm volatile("; edge tile" : "+v"(qm) : : "memory");   // side effect: the branch cannot be speculated / if-converted
+                // Most edge tiles need only ONE of the two conditions: a diagonal tile whose keys are all inside the
+                // window of all the wave's rows (causal test only), or a window-boundary tile whose keys are all
+                // causal (window test only).  One compare against a per-lane threshold instead of three per element.
+                const bool no_sink = k0 >= ns;
+                const bool all_in_window = k0 >= pw_hi - W + 1;
+                const bool all_causal = k0 + 63 <= pw0;
+                if (no_sink && all_in_window) {
+                    const int t = qm - k0 - 4 * h;                 // valid iff (32 kh + (i&3) + 8 (i>>2)) <= t
 #pragma unroll
-                for (int kh = 0; kh < 2; ++kh)
+                    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool valid = (key <= qm) && (key < ns || key + W > qm);
-                        s[kh][i] = valid ? s[kh][i] : -INFINITY;
-                    }
+                        for (int i = 0; i < 16; ++i) s[kh][i] = (32 * kh + (i & 3) + 8 * (i >> 2) <= t) ? s[kh][i] : -INFINITY;
+                } else if (no_sink && all_causal) {
+                    const int t = qm - W - k0 - 4 * h;             // valid iff (32 kh + ...) > t
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) s[kh][i] = (32 * kh + (i & 3) + 8 * (i >> 2) > t) ? s[kh][i] : -INFINITY;
+                } else {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = k0 + 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            const bool valid = (key <= qm) && (key < ns || key + W > qm);
+                            s[kh][i] = valid ? s[kh][i] : -INFINITY;
+                        }
+                }
             }
             float mx = -INFINITY;
 #pragma unroll
