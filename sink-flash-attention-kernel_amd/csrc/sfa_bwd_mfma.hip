@@ -459,11 +459,34 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel_ws(BwdArgs a) {
     constexpr int NST = 4;
     char* xch = smem + NST * STAGE;                   // [2 buffers][4 key groups][XBYTES]
 
+    // Longest first inside every XCD's share: a block that holds sink keys (block 0 when num_sink > 0) sweeps EVERY
+    // later query slice, twice the trips of a full window block; dispatched in plain (group, block) order the last
+    // group's block 0 starts three quarters into the kernel and ends it alone.  So each XCD (a contiguous range of
+    // (b, KV head) groups after xcd_remap) runs the block 0 of all its groups first, then the other blocks.
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int kb = bid % a.n_kblocks;
-    int rest = bid / a.n_kblocks;
-    const int hk = rest % a.Hkv;
-    const int b = rest / a.Hkv;
+    int kb, grp;
+    {
+        const int nK = a.n_kblocks, nG = (int)gridDim.x / nK;
+        const int chunk = nG >> 3;                        // groups per XCD
+        if (a.num_sink > 0 && nK > 1 && (nG & 7) == 0 && chunk > 0) {
+            const int per = chunk * nK, xcd = bid / per, j = bid - xcd * per;
+            if (j < chunk) {
+                grp = xcd * chunk + j;
+                kb = 0;
+            } else {
+                // (block-major over the XCD's groups, i.e. strictly longest-first, measured slightly slower and left
+                // the caches colder for the next kernel)
+                const int r2 = j - chunk;
+                grp = xcd * chunk + r2 / (nK - 1);
+                kb = 1 + r2 % (nK - 1);
+            }
+        } else {
+            kb = bid % nK;
+            grp = bid / nK;
+        }
+    }
+    const int hk = grp % a.Hkv;
+    const int b = grp / a.Hkv;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave & 3;
