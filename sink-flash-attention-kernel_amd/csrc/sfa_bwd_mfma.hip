@@ -910,7 +910,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dq_mfma_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int qt = bid % a.n_qtiles;
+    const int qt = a.n_qtiles - 1 - bid % a.n_qtiles;      // longest (latest) q tiles first, as in the forward
     int rest = bid / a.n_qtiles;
     const int hg = rest % a.hgroups;
     rest /= a.hgroups;

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
         const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     }
-    const int qt = bid % a.n_qtiles;
+    // q tiles from the END of the sequence first: a late tile walks the full window (or, causal, everything before it),
+    // an early one a few key tiles, so the short workgroups should be the ones that finish the kernel
+    const int qt = a.n_qtiles - 1 - bid % a.n_qtiles;
     int rest = bid / a.n_qtiles;
     const int hg = rest % a.hgroups;
     rest /= a.hgroups;
