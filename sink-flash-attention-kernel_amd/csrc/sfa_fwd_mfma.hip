@@ -211,6 +211,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_mfma_kernel(FwdArgs a) {
         issue_loads(tile_of(0));
         write_lds(0);
     }
+    // Q fragments landed, on EVERY path into the loop: without this the waitcnt pass still counts them as pending on
+    // the nt == 0 edge and the merged state makes it emit vmcnt(7..0) inside the QK^T chain, which drains the next
+    // tile's prefetch (issued a few instructions earlier) in the middle of every tile (C3 -1 %, causal -2 %)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();
 
     for (int it = 0; it < nt; ++it) {
