@@ -18,8 +18,10 @@ Extra objects on the JSON line:
   roofline      the dominant kernel of the step (the longest of: forward kernel, backward dK/dV kernel, backward dQ
                 kernel), its algorithmic FLOPs / its average duration measured with HIP events on the launching
                 stream inside the timed steps (sfa_debug_set_stage_events for the backward stages), against the
-                gfx950 dense bf16 MFMA peak 2516.6 TFLOP/s.  traffic: HBM bytes per launch from the committed
-                rocprofv3 PMC run (profiles/*_pmc.json) if present, else null.
+                gfx950 dense bf16 MFMA peak 2516.6 TFLOP/s.  per_kernel: ms / algorithmic TFLOP/s / fraction of peak of
+                all three kernels (fwd_frac repeats the forward's, north_star's 60 % target).  traffic: HBM bytes per
+                launch from the committed rocprofv3 PMC run (profiles/*_pmc.json) if present, else null;
+                traffic_source names that file (it is NOT measured inside this run).
   cpu_baseline  the reference's eager fp32 algorithm (oracle/sink_oracle.py restatement, dense N x N, torch on all
                 host cores) timed on a bounded slice of the same workload (1 batch element x 1 KV group = 4 q heads),
                 rank 0 at N=1 only.
@@ -88,13 +90,15 @@ def cpu_baseline(w):
 
 
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, if any."""
-    best = None
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (a separate
+    builder run, see tools/pmc_round.sh), and where it came from.  (None, None) when there is none."""
+    best = (None, None)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(path))
-            if kernel_key in d:
-                best = d[kernel_key].get("hbm_bytes_per_launch")
+            if kernel_key in d and d[kernel_key].get("hbm_bytes_per_launch") is not None:
+                best = (d[kernel_key]["hbm_bytes_per_launch"],
+                        f"profiles/{os.path.basename(path)} (builder rocprofv3 --pmc run of this kernel, not this run)")
         except Exception:
             pass
     return best
@@ -148,6 +152,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-slice", default=None, metavar="PATH",
+                    help="after the timed region run ONE more step and save the tensors of the last (batch, KV head) "
+                         "unit (q, k, v, dO, O, dQ, dK, dV) to PATH: tests/test_gpu_bench_contract.py checks them "
+                         "against the oracle, so the bench cannot go fast on a wrong answer")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the multi-rank control path (gloo, no kernels, value is meaningless)")
     args = ap.parse_args()
@@ -213,6 +221,19 @@ def main():
     f_f = flops_fwd(B, Hq, N, D, ns, W)
     value = job_value(f_fb, world, dt / args.steps)
 
+    if rank == 0 and args.dump_slice:
+        out = sink_flash_attention(q, k, v, num_sink=ns, window_size=W)
+        out.backward(do)
+        torch.cuda.synchronize()
+        g_ = Hq // Hkv
+        b_, hk_ = B - 1, Hkv - 1
+        hs = slice(hk_ * g_, (hk_ + 1) * g_)
+        cut = lambda t, h: t.detach()[b_:b_ + 1, h].cpu().clone()
+        torch.save({"q": cut(q, hs), "k": cut(k, slice(hk_, hk_ + 1)), "v": cut(v, slice(hk_, hk_ + 1)),
+                    "do": cut(do, hs), "o": cut(out, hs), "dq": cut(q.grad, hs), "dk": cut(k.grad, slice(hk_, hk_ + 1)),
+                    "dv": cut(v.grad, slice(hk_, hk_ + 1)), "ns": ns, "W": W}, args.dump_slice)
+        q.grad = k.grad = v.grad = None
+
     if rank == 0:
         fwd_ms = sorted(s.elapsed_time(e) for s, e in fwd_ev)
         fwd_avg = sum(fwd_ms) / len(fwd_ms)
@@ -229,10 +250,20 @@ def main():
         dom = max(kernels, key=lambda n: kernels[n][0] if kernels[n][0] == kernels[n][0] else -1)
         dur, fl, path = kernels[dom]
         achieved = fl / (dur * 1e-3) / 1e12 if dur and dur == dur and dur > 0 else None
+        per_kernel = {}
+        for name, (ms_, fl_, _p) in kernels.items():
+            tf = fl_ / (ms_ * 1e-3) / 1e12 if ms_ == ms_ and ms_ > 0 else None
+            per_kernel[name] = {"ms": round(ms_, 4), "algorithmic_tflops": round(tf, 1) if tf else None,
+                                "frac": round(tf / PEAK_BF16_TFLOPS, 4) if tf else None}
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"bound": "mfma", "kernel": f"{dom} ({path})",
                     "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
-                    "avg_launch_ms": round(dur, 4), "traffic": pmc_traffic(dom),
+                    "avg_launch_ms": round(dur, 4), "traffic": traffic,
+                    # NOT measured in this run: PMC counters need their own rocprofv3 pass (tools/pmc_round.sh)
+                    "traffic_source": traffic_src,
+                    "per_kernel": per_kernel,
+                    "fwd_frac": per_kernel["fwd"]["frac"],
                     "stage_ms": {"fwd": round(fwd_avg, 4), "bwd_preprocess": round(pre, 4),
                                  "bwd_dkdv": round(dkdv, 4), "bwd_dq": round(dq, 4)}}
         line = {

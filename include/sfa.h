@@ -22,7 +22,9 @@
  *     buffer (outputs and workspaces included) and passes DEVICE pointers.
  *   - Every launch goes to the hipStream_t passed as `stream` (void* here so the
  *     header needs no HIP include); the caller makes the right device current.
- *   - Re-entrant, no global mutable state except a thread-local error string.
+ *   - Re-entrant.  Mutable state inside the library: the thread-local error / path strings, a per-kernel bitmask of
+ *     the devices whose dynamic-LDS attribute has been set (atomic OR, idempotent) and the tuning knobs read once from
+ *     the environment (SFA_*) at first use.  Nothing else survives a call.
  *   - Return value: 0 = ok, <0 = SFA_ERR_* (argument / support problem, nothing
  *     was launched), >0 = a hipError_t from a launch.
  *   - Tensors are described by sfa_tensor: 4-D [B, H, N, D] with strides in
@@ -59,7 +61,7 @@ extern "C" {
  * (no extra workspace) where the MFMA backward does not apply. */
 #define SFA_FLAG_BWD_SPILL_DS 0x2u
 /* sfa_decode*: one launch instead of two.  The last KV split of a (batch, KV head) to finish folds the split partials
- * itself (atomic arrival counters).  Contract: the caller OWNS the workspace across calls and zero-initialised its last
+ * itself (atomic arrival counters).  Contract: the caller OWNS the workspace across calls and zero-initialised its FIRST
  * align256((B * Hkv + 1) * 4) bytes once; the kernel leaves them zero.  Worth it at small batch, where a decode step is
  * two ~10 us launches otherwise. */
 #define SFA_FLAG_DECODE_ONE_PASS 0x4u
@@ -130,6 +132,9 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
  *   cu_seqlens: DEVICE int32 [n_seq + 1], cu[0] = 0, cu[n_seq] = T; sequence i = rows cu[i] .. cu[i+1].  Every
  *   sequence gets its own mask origin (valid(i, j) in its own positions) and its own s_aux term.
  *   max_seqlen: longest sequence (only sizes the grids; an upper bound is fine).
+ *   The device array is NOT validated (no host synchronisation): cu must be non-decreasing with cu[0] = 0 and
+ *   max_seqlen must not understate the longest sequence, or tiles are silently dropped.  Rows behind cu[n_seq]
+ *   (padding) are never written: the caller zero-fills outputs / gradients if it hands in such a pack.
  *   Workspace of sfa_bwd_varlen: sfa_bwd_workspace_bytes(1, Hq, Hkv, T, D, dtype, num_sink, window, 0).
  * 16-bit dtypes and head dims 64 / 80 / 96 / 128 only (sfa_varlen_supported); SFA_ERR_UNSUPPORTED otherwise - the
  * caller can then run the sequences one by one through sfa_fwd / sfa_bwd on strided views.
@@ -151,6 +156,8 @@ int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v
  * decode_kernel.py:72-83).
  *   q,o [B, Hq, 1, D]   k,v [B, Hkv, Nkv, D]   s_aux nullable [Hq] float32
  */
+/* Monotonic in Nkv: a workspace sized for Nkv serves every call with the same (B, Hq, Hkv, D, dtype) and FEWER keys
+ * (a ring cache sizes it once for num_sink + window_size and steps through every fill level). */
 size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D,
                                   int dtype);
 

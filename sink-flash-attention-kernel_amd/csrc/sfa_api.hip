@@ -275,8 +275,10 @@ int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v
 size_t sfa_decode_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype) {
     DecodePlan pl;
     if (decode_plan(B, Hq, Hkv, Nkv, D, dtype, &pl) != SFA_OK) return 0;
-    // split partials, then the int32 counters [B * Hkv + 1] of the one-pass mode
-    return align256((size_t)B * Hq * pl.splits * (size_t)(D + 2) * sizeof(float)) + align256((size_t)(B * Hkv + 1) * sizeof(int));
+    // int32 counters [B * Hkv + 1] of the one-pass mode (fixed place: the start), then the split partials.  Sized for
+    // pl.max_splits, the largest split count ANY key count <= Nkv can plan (the split count itself is not monotonic
+    // in Nkv once the workgroup target caps it), so a workspace sized for a ring's capacity serves every fill level.
+    return decode_counter_bytes(B, Hkv) + align256((size_t)B * Hq * pl.max_splits * (size_t)(D + 2) * sizeof(float));
 }
 
 }  // extern "C"

@@ -1621,10 +1621,8 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
         a.ds = (char*)workspace + consts_bytes(p) + ds_table_bytes(p);
         a.ds_chunks = ds_chunks_per_head(p);
     }
-    {
-        const char* e = getenv("SFA_DS_NT");
-        a.ds_nt = e ? atoi(e) : 1;
-    }
+    static const int ds_nt_knob = env_int("SFA_DS_NT", 1);
+    a.ds_nt = ds_nt_knob;
     a.B = p.B; a.Hq = p.Hq; a.Hkv = p.Hkv; a.N = p.N;
     a.num_sink = p.num_sink;
     a.window = p.window < 0 ? 0 : (p.window > a.Nk ? a.Nk : p.window);
@@ -1637,10 +1635,8 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.rb = 8 / a.hpw;
     a.n_qtiles = (int)cdiv64(p.N, 32 * a.rb);
     a.hgroups = g / a.hpw;
-    {
-        const char* e = getenv("SFA_WS_PRIO");
-        a.prio = e ? atoi(e) : 1;
-    }
+    static const int ws_prio_knob = env_int("SFA_WS_PRIO", 1);
+    a.prio = ws_prio_knob;
     if ((int64_t)a.n_qtiles * a.hgroups * p.Hkv * p.B >= (1ll << 31)) {
         set_error("bwd_mfma: grid too large");
         return SFA_ERR_UNSUPPORTED;

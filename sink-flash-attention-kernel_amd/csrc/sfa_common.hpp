@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "sfa.h"
 
@@ -33,10 +34,18 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(*flags & bit)) {
+    // two threads may both set the (idempotent) attribute; the flag word itself is only ever OR-ed atomically
+    if (!(__atomic_load_n(flags, __ATOMIC_ACQUIRE) & bit)) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        *flags |= bit;
+        __atomic_fetch_or(flags, bit, __ATOMIC_RELEASE);
     }
+}
+
+// integer tuning knob from the environment, read ONCE per call site (getenv is not free and not thread-safe against
+// setenv): static const int knob = env_int("SFA_X", default);
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 inline int launch_status(const char* what) {

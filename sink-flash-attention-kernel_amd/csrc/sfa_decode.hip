@@ -427,6 +427,7 @@ int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int 
     int64_t kps = cdiv64(cdiv64(Nkv > 0 ? Nkv : 1, want), iter_keys) * iter_keys;
     int64_t splits = cdiv64(Nkv > 0 ? Nkv : 1, kps);
     plan->splits = (int)splits;
+    plan->max_splits = (int)want;          // splits <= want for every key count <= Nkv (want is monotonic in Nkv)
     plan->keys_per_split = (int)kps;
     plan->lpk = lpk;
     plan->gt = gt;
@@ -446,13 +447,13 @@ int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v,
     if (k_new && v_new && (new_slot >= 0 || dyn_state))
         fr = Fresh{make_view(k_new), make_view(v_new), dyn_state ? 0 : new_slot, dyn_state, wsize};
     const int S = pl.splits;
-    float* Mp = reinterpret_cast<float*>(workspace);
+    // counters of the one-pass mode sit at the START of the workspace (their place must not move when the split count
+    // changes from one step to the next while a ring fills), the partials behind them
+    float* Mp = reinterpret_cast<float*>((char*)workspace + decode_counter_bytes(B, Hkv));
     float* Lp = Mp + (int64_t)B * Hq * S;
     float* Op = Lp + (int64_t)B * Hq * S;
-    // counters of the one-pass mode live behind the partials (256-byte aligned)
-    const size_t part_bytes = (((size_t)B * Hq * S * (size_t)(D + 2) * sizeof(float)) + 255) & ~(size_t)255;
     one_pass = one_pass && D <= 256;      // the in-kernel fold gives a head to one wave: 64 lanes x 4 columns
-    OnePass op1{one_pass ? reinterpret_cast<int*>((char*)workspace + part_bytes) : nullptr, s_aux, make_view(o)};
+    OnePass op1{one_pass ? reinterpret_cast<int*>(workspace) : nullptr, s_aux, make_view(o)};
     dim3 grid(S, Hkv, B);
     int st;
     if (q->dtype == SFA_DTYPE_F32)

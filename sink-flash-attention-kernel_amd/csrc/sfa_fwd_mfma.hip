@@ -442,10 +442,8 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     // workgroup, prologue / epilogue bound) two 4-wave workgroups per CU overlap each other's latencies:
     // measured C2 (W=1024) +7 %, gpt-oss sliding layers (W=128) +8..12 %, C3 (W=4096) -3 %
     int NW = (p.window >= 0 && p.window <= 2048) ? 4 : 8;
-    if (const char* e = getenv("SFA_FWD_NW")) {
-        const int x = atoi(e);
-        if (x == 4 || x == 8) NW = x;
-    }
+    static const int nw_knob = env_int("SFA_FWD_NW", 0);
+    if (nw_knob == 4 || nw_knob == 8) NW = nw_knob;
     const int g = p.Hq / p.Hkv;
     FwdArgs a;
     a.q = make_view(q); a.k = make_view(k); a.v = make_view(v); a.o = make_view(o);
@@ -460,10 +458,8 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
     a.rb = NW / a.hpw;
     a.n_qtiles = (int)cdiv64(p.N, 32 * a.rb);
     a.hgroups = g / a.hpw;
-    {
-        const char* e = getenv("SFA_FWD_PRIO");
-        a.prio = e ? atoi(e) : 1;
-    }
+    static const int prio_knob = env_int("SFA_FWD_PRIO", 1);
+    a.prio = prio_knob;
     a.q_range = slice_range(q); a.k_range = slice_range(k); a.v_range = slice_range(v); a.o_range = slice_range(o);
     const int64_t nblk = (int64_t)a.n_qtiles * a.hgroups * p.Hkv * p.B;
     if (nblk >= (1ll << 31)) {

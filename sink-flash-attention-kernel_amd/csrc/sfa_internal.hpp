@@ -37,7 +37,10 @@ struct DecodePlan {
     int keys_per_split;  // multiple of the keys one workgroup iteration covers
     int lpk;             // lanes per key row (power of two)
     int gt;              // q heads of a GQA group processed per pass
+    int max_splits;      // upper bound of `splits` over every key count <= the planned one (workspace sizing)
 };
+// int32 arrival counters of the one-pass decode, at the start of the decode workspace
+inline size_t decode_counter_bytes(int64_t B, int64_t Hkv) { return (((size_t)(B * Hkv + 1) * sizeof(int)) + 255) & ~(size_t)255; }
 int decode_plan(int64_t B, int64_t Hq, int64_t Hkv, int64_t Nkv, int64_t D, int dtype, DecodePlan* plan);
 // keys = rows [0, n1) of (k, v) followed by rows [0, n2) of (k2, v2); k2/v2 may be null when n2 == 0
 int decode_launch(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, int64_t n1, const sfa_tensor* k2,

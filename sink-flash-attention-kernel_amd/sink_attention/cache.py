@@ -194,8 +194,14 @@ class SinkCacheLayer(_HFLayer if _HAS_HF else object):
         st = getattr(self, "_dev_state", None)
         if st is not None:
             sl, wl, wp = st.tolist()
-            self.seen_tokens += (wl - self.window_len) if wl < self.window_size or self.window_len < self.window_size \
-                else ((wp - self.write_pos) % self.window_size)
+            W = self.window_size
+            if wl < W:                       # still filling: one slot per step
+                steps = wl - self.window_len
+            elif self.window_len < W:        # filled up since the last pull: the step that took the last slot wrapped
+                steps = (W - self.window_len) + wp          # write_pos to 0, every later step advanced it by one
+            else:                            # full before and after (steps counted modulo the ring size)
+                steps = (wp - self.write_pos) % W
+            self.seen_tokens += steps
             self.sink_len, self.window_len, self.write_pos = sl, wl, wp
 
     def decode_step_dyn(self, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor,

@@ -9,12 +9,16 @@ whole pack is ONE launch per kernel.  Shapes the packed kernels do not cover (fp
 unaligned views) run sequence by sequence through the ordinary op on strided views (no input copies).
 """
 import math
+import os
 from typing import List, Sequence, Union
 
 import torch
 
 from . import _native as N
 from .sink_flash_attention import _sink_flash_attention_ex
+
+
+_CHECK_CU = os.environ.get("SINK_ATTENTION_CHECK_CU", "0") == "1"
 
 
 def seq_bounds_from_position_ids(position_ids: torch.Tensor) -> List[int]:
@@ -30,14 +34,18 @@ class SinkFlashAttentionVarlenFunc(torch.autograd.Function):
     """One launch per kernel for the whole pack; same saved state as SinkFlashAttentionFunc plus cu_seqlens."""
 
     @staticmethod
-    def forward(ctx, q, k, v, cu_dev, max_seqlen, num_sink, window_size, s_aux):
+    def forward(ctx, q, k, v, cu_dev, max_seqlen, num_sink, window_size, s_aux, checked=True):
         _, H_q, T, D = q.shape
+        # A device cu_seqlens handed in with max_seqlen is NOT validated (that would be a host synchronisation): rows it
+        # does not cover (padding behind cu[-1], an understated max_seqlen) are then never written by the kernels, so
+        # outputs and gradients start from zeros instead of uninitialised memory on that path.
+        alloc = torch.empty if checked else torch.zeros
         use_s_aux = s_aux is not None
         s_aux_f = s_aux.detach().contiguous().float() if use_s_aux else None
         scale = 1.0 / math.sqrt(D)
         q, k, v = N.unit_inner(q), N.unit_inner(k), N.unit_inner(v)
-        o = torch.empty((1, H_q, T, D), device=q.device, dtype=q.dtype)
-        lse = torch.empty((H_q, T), device=q.device, dtype=torch.float32)
+        o = alloc((1, H_q, T, D), device=q.device, dtype=q.dtype)
+        lse = alloc((H_q, T), device=q.device, dtype=torch.float32)
         lib = N.lib()
         with torch.cuda.device(q.device):
             st = lib.sfa_fwd_varlen(N.desc(q), N.desc(k), N.desc(v), N.desc(o), lse.data_ptr(),
@@ -45,22 +53,23 @@ class SinkFlashAttentionVarlenFunc(torch.autograd.Function):
                                     max_seqlen, num_sink, window_size, scale, 0, N.stream_ptr(q.device))
         N.check(st, "sfa_fwd_varlen")
         ctx.save_for_backward(q, k, v, o, lse, cu_dev, s_aux_f if use_s_aux else torch.empty(0, device=q.device))
-        ctx.cfg = (max_seqlen, num_sink, window_size, scale, use_s_aux, s_aux.dtype if use_s_aux else None)
+        ctx.cfg = (max_seqlen, num_sink, window_size, scale, use_s_aux, s_aux.dtype if use_s_aux else None, checked)
         return o
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, do):
         q, k, v, o, lse, cu_dev, s_aux_f = ctx.saved_tensors
-        max_seqlen, num_sink, window_size, scale, use_s_aux, s_aux_dtype = ctx.cfg
+        max_seqlen, num_sink, window_size, scale, use_s_aux, s_aux_dtype, checked = ctx.cfg
+        alloc = torch.empty if checked else torch.zeros
         _, H_q, T, D = q.shape
         H_kv = k.shape[1]
         do = N.unit_inner(do)
         if do.dtype != q.dtype:
             do = do.to(q.dtype)
-        dq = torch.empty((1, H_q, T, D), device=q.device, dtype=q.dtype)
-        dk = torch.empty((1, H_kv, T, D), device=q.device, dtype=q.dtype)
-        dv = torch.empty((1, H_kv, T, D), device=q.device, dtype=q.dtype)
+        dq = alloc((1, H_q, T, D), device=q.device, dtype=q.dtype)
+        dk = alloc((1, H_kv, T, D), device=q.device, dtype=q.dtype)
+        dv = alloc((1, H_kv, T, D), device=q.device, dtype=q.dtype)
         ds_aux = torch.empty((H_q,), device=q.device, dtype=torch.float32) if use_s_aux else None
         lib = N.lib()
         ws_bytes = lib.sfa_bwd_workspace_bytes(1, H_q, H_kv, T, D, N.SFA_DTYPE[q.dtype], num_sink, window_size, 0)
@@ -74,7 +83,7 @@ class SinkFlashAttentionVarlenFunc(torch.autograd.Function):
         N.check(st, "sfa_bwd_varlen")
         if use_s_aux and ds_aux.dtype != s_aux_dtype:
             ds_aux = ds_aux.to(s_aux_dtype)
-        return dq, dk, dv, None, None, None, None, ds_aux
+        return dq, dk, dv, None, None, None, None, ds_aux, None
 
 
 def _aligned(t: torch.Tensor) -> bool:
@@ -105,8 +114,18 @@ def sink_flash_attention_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         qq, kk, vv = N.unit_inner(q), N.unit_inner(k), N.unit_inner(v)
         native = _aligned(qq) and _aligned(kk) and _aligned(vv)
     if native:
+        checked = True
         if isinstance(cu_seqlens, torch.Tensor) and cu_seqlens.is_cuda and max_seqlen is not None:
+            # trusted as given (contract, include/sfa.h sfa_fwd_varlen): cu[0] == 0, non-decreasing, cu[-1] <= T,
+            # max_seqlen >= the longest sequence.  SINK_ATTENTION_CHECK_CU=1 validates it (one host synchronisation).
             cu_dev = cu_seqlens.to(torch.int32).contiguous()
+            checked = False
+            if _CHECK_CU:
+                cu = cu_dev.tolist()
+                assert len(cu) >= 2 and cu[0] == 0 and cu[-1] <= T, f"bad cu_seqlens {cu} for T={T}"
+                assert all(b >= a for a, b in zip(cu[:-1], cu[1:])), f"cu_seqlens must be non-decreasing: {cu}"
+                assert max_seqlen >= max(b - a for a, b in zip(cu[:-1], cu[1:])), "max_seqlen understates the longest sequence"
+                checked = cu[-1] == T
         else:
             cu = cu_seqlens.tolist() if isinstance(cu_seqlens, torch.Tensor) else list(cu_seqlens)
             assert len(cu) >= 2 and cu[0] == 0 and cu[-1] == T, f"bad cu_seqlens {cu} for T={T}"
@@ -116,7 +135,7 @@ def sink_flash_attention_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         if T == 0 or max_seqlen == 0:
             return torch.empty_like(q)
         return SinkFlashAttentionVarlenFunc.apply(q, k, v, cu_dev, int(min(max_seqlen, T)), int(num_sink),
-                                                  int(window_size), s_aux)
+                                                  int(window_size), s_aux, checked)
 
     # sequence by sequence on strided views (fp32, head dims without a packed kernel, unaligned views)
     cu = cu_seqlens.tolist() if isinstance(cu_seqlens, torch.Tensor) else list(cu_seqlens)

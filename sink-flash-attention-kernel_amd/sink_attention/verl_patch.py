@@ -96,7 +96,9 @@ def _sink_flash_attention_forward(query_states, key_states, value_states, attent
     # N_q < N_kv with N_q > 1 (chunked prefill against a cache; the reference would hand it to the decode kernel and
     # fail its N_q == 1 assert): the prefill kernels take the queries as the last N_q key positions
 
-    window_size = sliding_window if sliding_window is not None else N_q
+    # full-attention layer (sliding_window None): every row sees all the keys before it, i.e. the window is the KEY
+    # count (N_q would cut a chunk's rows off from the cached keys)
+    window_size = sliding_window if sliding_window is not None else N_kv
     out = _sink_flash_attention_ex(q, k, v, 0, window_size, s_aux=s_aux_local, out_bnhd=True)
     return out.transpose(1, 2)              # already contiguous [B, N, H, D]
 

@@ -11,9 +11,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_json_contract():
+def test_bench_json_contract(tmp_path):
+    dump = str(tmp_path / "slice.pt")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-cpu-baseline", "--dump-slice", dump], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -34,3 +36,17 @@ def test_bench_json_contract():
     assert abs(d["value"] - gflop / d["ms_per_step"]) / d["value"] < 1e-2
     assert 0.8 < sum(r["stage_ms"].values()) / d["ms_per_step"] <= 1.02
     assert 100.0 < d["value"] < 2516.6
+    assert set(r["per_kernel"]) == {"fwd", "bwd_dkdv", "bwd_dq"} and r["fwd_frac"] == r["per_kernel"]["fwd"]["frac"]
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+
+    # the numbers above must belong to a RIGHT answer: one (batch, KV head) unit of the bench's own tensors (results of
+    # one more step on the same inputs) against the banded fp64 oracle, tolerances of the C3 parity test
+    import torch
+    from util import assert_close, oracle_bwd, oracle_fwd
+    t = torch.load(dump)
+    o_r, _ = oracle_fwd(t["q"], t["k"], t["v"], t["ns"], t["W"], banded=True)
+    dq_r, dk_r, dv_r, _ = oracle_bwd(t["q"], t["k"], t["v"], t["do"], t["ns"], t["W"], banded=True)
+    assert_close(t["o"], o_r.bfloat16(), 2e-2, 2e-2, "bench fwd")
+    assert_close(t["dq"], dq_r, 5e-2, 5e-2, "bench dq")
+    assert_close(t["dk"], dk_r, 1e-1, 5e-2, "bench dk")
+    assert_close(t["dv"], dv_r, 1e-1, 5e-2, "bench dv")

@@ -45,6 +45,26 @@ def test_boundary_backward_through_bnhd_layout():
     assert maxdiff(sa.grad, dsa) < 1e-4
 
 
+@pytest.mark.parametrize("sliding_window", [None, 40])
+def test_chunked_prefill_against_a_cache(sliding_window):
+    """N_q < N_kv with N_q > 1 (a prefill chunk against cached keys; the reference asserts N_q == N_kv): the chunk's
+    rows are the LAST N_q key positions.  A full-attention layer (sliding_window=None) must see ALL earlier keys, not
+    just the chunk (the window is the key count, not N_q)."""
+    from sink_attention.verl_patch import _sink_flash_attention_forward as fwd
+    from oracle import sink_oracle as O
+    g = torch.Generator().manual_seed(31)
+    B, Nq, Nkv, Hq, Hkv, D = 1, 16, 300, 4, 2, 64
+    qs = torch.randn(B, Nq, Hq, D, generator=g).bfloat16().to(DEV)
+    ks = torch.randn(B, Nkv, Hkv, D, generator=g).bfloat16().to(DEV)
+    vs = torch.randn(B, Nkv, Hkv, D, generator=g).bfloat16().to(DEV)
+    sa = (torch.randn(Hq, generator=g) * 0.5).to(DEV)
+    out = fwd(qs, ks, vs, None, Nq, is_causal=True, sliding_window=sliding_window, s_aux=sa)
+    t = lambda x: x.detach().cpu().transpose(1, 2)
+    W = sliding_window if sliding_window is not None else Nkv
+    ref, _ = O.sink_attention_dense(t(qs), t(ks), t(vs), 0, W, sa.cpu())
+    assert out.shape == qs.shape and maxdiff(t(out), ref) < 2e-2
+
+
 def test_fallback_and_patch_roundtrip_on_gpu():
     import transformers.modeling_flash_attention_utils as fa_utils
     import sink_attention.verl_patch as vp

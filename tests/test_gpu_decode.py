@@ -288,6 +288,47 @@ def test_decode_step_in_a_hip_graph_with_device_state():
         assert torch.equal(a.window_k, b.window_k) and torch.equal(a.window_v, b.window_v)
 
 
+def test_pull_state_counts_tokens_across_the_fill_boundary():
+    """Device-resident state stepped from a not-yet-full ring past the point where it fills: pull_state() must count
+    every step (fill steps + the steps after the wrap), and the twin stepped on the host agrees in every counter."""
+    from sink_attention.cache import SinkCacheLayer
+    g = torch.Generator().manual_seed(5)
+    B, Hq, Hkv, D, ns, W = 1, 4, 2, 64, 2, 12
+    a, b = SinkCacheLayer(ns, W), SinkCacheLayer(ns, W)
+    kp, vp = rand((B, Hkv, ns + W - 3, D), g, torch.float16).to(DEV), rand((B, Hkv, ns + W - 3, D), g, torch.float16).to(DEV)
+    a.update(kp, vp)
+    b.update(kp, vp)
+    assert a.window_len == W - 3
+    a.enable_device_state()
+    for _ in range(8):     # 3 steps fill the ring, 5 more wrap
+        q = rand((B, Hq, 1, D), g, torch.float16).to(DEV)
+        kn, vn = rand((B, Hkv, 1, D), g, torch.float16).to(DEV), rand((B, Hkv, 1, D), g, torch.float16).to(DEV)
+        o1 = a.decode_step_dyn(q, kn, vn)
+        o2 = b.decode_step(q, kn, vn)
+        assert torch.equal(o1, o2)
+    a.pull_state()
+    assert (a.sink_len, a.window_len, a.write_pos, a.seen_tokens) == (b.sink_len, b.window_len, b.write_pos, b.seen_tokens)
+
+
+def test_ring_step_workspace_serves_every_fill_level():
+    """B * H_kv = 64: the split count is capped by the workgroup target and is not monotonic in the key count; the
+    workspace the cache sizes ONCE for the full ring must serve every fill level (it raised SFA_ERR_WORKSPACE
+    mid-generation before the workspace query became monotonic)."""
+    from sink_attention.cache import SinkCacheLayer
+    g = torch.Generator().manual_seed(6)
+    B, Hq, Hkv, D, ns, W = 8, 32, 8, 128, 4, 16384
+    a = SinkCacheLayer(ns, W)
+    n0 = 6600
+    kp = rand((B, Hkv, n0, D), g, torch.bfloat16).to(DEV)
+    a.update(kp, kp)
+    q = rand((B, Hq, 1, D), g, torch.bfloat16).to(DEV)
+    kn = rand((B, Hkv, 1, D), g, torch.bfloat16).to(DEV)
+    for _ in range(80):          # crosses N_kv = 6657, where the planned split count jumps above the full ring's
+        out = a.decode_step(q, kn, kn)
+    kc, vc = a.get_kv()
+    assert maxdiff(out[:1], O.decode_dense(q[:1].cpu(), kc[:1].cpu(), vc[:1].cpu())) < 2e-2
+
+
 def test_one_pass_decode_matches_two_launches():
     """SFA_FLAG_DECODE_ONE_PASS (the last split to arrive folds the partials inside the split kernel) against the
     default two-launch decode, through the cache's fused step, over several steps (the arrival counters must be left

@@ -345,6 +345,50 @@ def test_mfma_path_is_used_for_headline_shapes():
             assert "mfma" in _path(), _path()
 
 
+@pytest.mark.parametrize("B,Hkv", [(2, 4), (4, 4), (2, 8), (3, 8)])
+def test_backward_with_many_kv_groups(B, Hkv):
+    """B * H_kv = 8, 16 (and 24: three groups per XCD share): the dK/dV kernels order their workgroups per XCD (heavy
+    sink blocks first) with index arithmetic that only engages when the (batch, KV head) count is a multiple of 8 -
+    the branch the C3 bench runs (B * H_kv = 32).  Several key blocks, sinks, a window shorter than N, GQA."""
+    Hq, N, D, ns, W = 2 * Hkv, 600, 128, 4, 200
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.bfloat16, seed=7 + B * Hkv)
+    do = rand((B, Hq, N, D), g, torch.bfloat16)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+    out.backward(do.to(DEV))
+    assert "mfma" in _path(), _path()
+    o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
+    dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
+    assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "fwd")
+    assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
+    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
+    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+    assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
+
+
+def test_baseline_c4_full_shape():
+    """BASELINE.json configs[3] at its REAL shape: gpt-oss-20b sliding layer, bf16, H_q=64, H_kv=8, D=80, N=8192,
+    window=128, s_aux, fwd+bwd including ds_aux, against the banded oracle (cheap at W=128)."""
+    B, Hq, Hkv, N, D, ns, W = 1, 64, 8, 8192, 80, 0, 128
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.bfloat16, seed=20)
+    do = rand((B, Hq, N, D), g, torch.bfloat16)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    o_r, _ = oracle_fwd(q, k, v, ns, W, sa, banded=True)
+    dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa, banded=True)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+    out.backward(do.to(DEV))
+    assert "mfma" in _path(), _path()
+    assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "C4 fwd")
+    assert_close(qd.grad, dq_r, 5e-2, 5e-2, "C4 dq")
+    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "C4 dk")
+    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "C4 dv")
+    assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
+
+
 @pytest.mark.parametrize("cfg", ["C2", "C3slice", "C4slice"])
 def test_baseline_config_shapes_against_banded_oracle(cfg):
     """BASELINE.json configs at full N on a slice of (batch, heads) small enough for the CPU oracle."""

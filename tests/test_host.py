@@ -47,6 +47,22 @@ def test_workspace_queries_need_no_gpu():
     assert b"16 bytes" in lib.sfa_last_error()
 
 
+@pytest.mark.parametrize("B,Hq,Hkv,D,cap", [(8, 32, 8, 128, 16388), (16, 16, 16, 64, 8196), (1, 8, 8, 128, 4100),
+                                             (32, 32, 32, 128, 4100)])
+def test_decode_workspace_is_monotonic_in_the_key_count(B, Hq, Hkv, D, cap):
+    """A ring cache sizes its decode workspace once for num_sink + window_size keys and then steps through every
+    fill level: the query must never report MORE for fewer keys (the planned split count alone is not monotonic)."""
+    from sink_attention import _native
+    lib = _native.lib()
+    full = lib.sfa_decode_workspace_bytes(B, Hq, Hkv, cap, D, 2)
+    prev = 0
+    for n in list(range(1, 600)) + list(range(600, cap + 1, 37)) + [cap]:
+        ws = lib.sfa_decode_workspace_bytes(B, Hq, Hkv, n, D, 2)
+        assert 0 < ws <= full, (n, ws, full)
+        assert ws >= prev, (n, ws, prev)
+        prev = ws
+
+
 def test_invalid_arguments_are_rejected_before_any_launch():
     from sink_attention import _native as N
     lib = N.lib()
