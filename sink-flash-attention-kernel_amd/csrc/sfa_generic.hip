@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void bwd_preprocess_kernel(View o, View d_o, c
 // Same contract for 16-bit tensors with 16-byte aligned rows (every MFMA-path call): a row is spread over LPR lanes
 // x 16 bytes, so one wave instruction fetches 64 / LPR whole rows (1 KiB, coalesced) and all of a wave's 16 rows of O
 // and dO are in flight at once.  HBM-bound: reads O and dO once.  Optionally also emits the row constants of the
-// wave-specialised dK/dV kernel (consts[b,h,0,:] = -LSE*log2e, consts[b,h,1,:] = -Delta) instead of a separate pass.
+// dK/dV kernels (consts[b,h,0,:] = -LSE * lse_factor, consts[b,h,1,:] = -Delta) instead of a separate pass.
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void bwd_preprocess_vec_kernel(View o, View d_o, const float* __restrict__ lse,
                                                                 const float* __restrict__ s_aux,
                                                                 float* __restrict__ delta,
                                                                 float* __restrict__ dsaux_part,
-                                                                float* __restrict__ consts, Problem p) {
+                                                                float* __restrict__ consts, Problem p, float lse_factor) {
     constexpr int RPI = 64 / LPR;                      // rows per wave instruction
     constexpr int NI = (kPreRows / kWaves) / RPI;      // instructions per wave (16 rows)
     __shared__ float part[kWaves];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void bwd_preprocess_vec_kernel(View o, View d_
             delta[rowbase + i] = s;
             const float ls = lse[rowbase + i];
             if (consts) {
-                consts[rowbase * 2 + i] = -ls * kLog2e;
+                consts[rowbase * 2 + i] = -ls * lse_factor;
                 consts[rowbase * 2 + p.N + i] = -s;
             }
             if (s_aux) wsum -= expf(sa - ls) * s;
@@ -458,13 +458,13 @@ bool bwd_preprocess_vectorised(const sfa_tensor* o, const sfa_tensor* d_o, const
 }
 
 int bwd_preprocess(const sfa_tensor* o, const sfa_tensor* d_o, const float* lse, const float* s_aux, float* delta,
-                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream, float* consts) {
+                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream, float* consts, float lse_factor) {
     const int nblk = (int)cdiv64(p.N, kPreRows);
     dim3 grid(nblk, p.Hq, p.B), block(256);
     const bool vec = bwd_preprocess_vectorised(o, d_o, p);
     if (vec) {
         const int lpr = p.D <= 32 ? 4 : (p.D <= 64 ? 8 : 16);
-#define SFA_PRE(TT, L) bwd_preprocess_vec_kernel<TT, L><<<grid, block, 0, stream>>>(make_view(o), make_view(d_o), lse, s_aux, delta, dsaux_part, consts, p)
+#define SFA_PRE(TT, L) bwd_preprocess_vec_kernel<TT, L><<<grid, block, 0, stream>>>(make_view(o), make_view(d_o), lse, s_aux, delta, dsaux_part, consts, p, lse_factor)
         if (o->dtype == SFA_DTYPE_BF16) {
             if (lpr == 4) SFA_PRE(bf16_t, 4); else if (lpr == 8) SFA_PRE(bf16_t, 8); else SFA_PRE(bf16_t, 16);
         } else {

@@ -10,7 +10,8 @@ int fwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, c
 // consts (optional, 16-bit tensors with 16-byte aligned rows only): [B, Hq, 2, N] row constants of the wave-specialised
 // dK/dV kernel, written in the same pass
 int bwd_preprocess(const sfa_tensor* o, const sfa_tensor* d_o, const float* lse, const float* s_aux, float* delta,
-                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream, float* consts = nullptr);
+                   float* dsaux_part, float* ds_aux, const Problem& p, hipStream_t stream, float* consts = nullptr,
+                   float lse_factor = 0.f);
 bool bwd_preprocess_vectorised(const sfa_tensor* o, const sfa_tensor* d_o, const Problem& p);   // can it emit consts?
 int64_t bwd_preprocess_nblk(int64_t N);
 int bwd_generic(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
@@ -29,7 +30,8 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
              const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,
              const sfa_tensor* dv, void* workspace, const Problem& p, unsigned flags, hipStream_t stream,
              bool consts_ready = false);
-bool bwd_mfma_wants_consts();   // the default dK/dV kernel reads the row constants from the head of its workspace
+bool bwd_mfma_wants_consts();   // the default dK/dV kernels read the row constants from the head of the workspace
+float bwd_mfma_lse_factor(const Problem& p);   // ... whose first row is -LSE * this factor
 
 // sfa_decode.hip
 struct DecodePlan {

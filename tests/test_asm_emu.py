@@ -1,0 +1,69 @@
+"""CPU: the generated (hand-placed) dK/dV kernel body, run instruction by instruction in the gfx950 emulator
+(tools/asmgen/emu.py), against the oracle.  The SAME instruction list is what csrc/gen/dkdv_asm.inc carries to the GPU
+(tools/asmgen/emit.py); the emulator additionally checks every s_waitcnt (no register touched while a load into it is
+outstanding) and the LDS-DMA / barrier protocol of the slice ring.  Also: the list assembles with the ROCm assembler,
+and the scheduler's output computes bit for bit what the program order computes."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from asmgen.asmcheck import CLANG, assemble          # noqa: E402
+from asmgen.dkdv import DkdvGen                       # noqa: E402
+from asmgen.harness import run_dkdv                   # noqa: E402
+from oracle import sink_oracle as O                   # noqa: E402
+
+_PROGS = {}
+
+
+def _prog(dtype, sched):
+    key = (dtype, sched)
+    if key not in _PROGS:
+        _PROGS[key] = DkdvGen(dtype, sched=sched).build()
+    return _PROGS[key]
+
+
+def _case(B, Hq, Hkv, N, Nk, ns, W, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    D = 128
+    q, do = (torch.randn(B, Hq, N, D, generator=g).to(td) for _ in range(2))
+    k, v = (torch.randn(B, Hkv, Nk, D, generator=g).to(td) for _ in range(2))
+    o, lse = O.sink_attention_dense(q, k, v, ns, W)
+    delta = (do.double() * o).sum(-1)
+    _, dk, dv, _ = O.sink_attention_bwd_dense(q, k, v, do, ns, W)
+    return q, k, v, do, lse, delta, dk, dv
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,Nk,ns,W,dtype", [
+    (1, 4, 1, 300, 300, 4, 100, "bf16"),      # two key blocks, GQA group of 4, sink + window, ragged last slice
+    (1, 2, 2, 333, 333, 70, 50, "f16"),       # sinks spanning three 32-key sub-blocks
+    (2, 2, 1, 77, 200, 3, 64, "bf16"),        # N_q < N_kv (queries are the last 77 positions)
+    (1, 2, 1, 40, 40, 4, 1, "bf16"),          # window of one key
+])
+def test_dkdv_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype):
+    q, k, v, do, lse, delta, dk, dv = _case(B, Hq, Hkv, N, Nk, ns, W, dtype, seed=N)
+    dk_e, dv_e = run_dkdv(_prog(dtype, True), q, k, v, do, lse, delta, ns, W, dtype)
+    # tolerance of the GPU parity tests for 16-bit gradients (tests/test_gpu_prefill.py): atol 1e-1 + rtol 5e-2
+    for got, ref, name in ((dk_e, dk, "dk"), (dv_e, dv, "dv")):
+        err = (got.double() - ref).abs()
+        assert (err <= 1e-1 + 5e-2 * ref.abs()).all(), (name, err.max().item())
+        assert err.max().item() < 4e-2, (name, err.max().item())
+
+
+def test_scheduled_body_equals_program_order_bitwise():
+    q, k, v, do, lse, delta, _, _ = _case(1, 2, 1, 96, 290, 4, 70, "bf16", seed=5)
+    a = run_dkdv(_prog("bf16", False), q, k, v, do, lse, delta, 4, 70, "bf16")
+    b = run_dkdv(_prog("bf16", True), q, k, v, do, lse, delta, 4, 70, "bf16")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm assembler not installed")
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_body_assembles_for_gfx950(dtype):
+    ok, err = assemble(_prog(dtype, True))
+    assert ok, err[:4000]

@@ -1,0 +1,543 @@
+"""Generator of the hand-placed dK/dV backward kernel body (gfx950, head dim 128, bf16 / f16).
+
+Replaces _sink_flash_attn_bwd_dkdv_kernel of the reference (sink_attention/sink_flash_attention.py:256-364) plus
+its PyTorch GQA group sum (:648-651); same maths as csrc/sfa_bwd_mfma.hip's wave-specialised kernel, different
+machine mapping:
+
+  workgroup = 4 waves = 256 keys of one (batch, KV head); wave w owns keys [64w, 64w+64) as two 32-key blocks and keeps
+  dK^T / dV^T of them in all 256 accumulator registers (one wave per SIMD, 512-register waves).  The workgroup sweeps
+  the q heads of the GQA group x the 32-row query slices that can see its keys ("trips").  Per trip and wave:
+      S'[q,key]  = Q K^T - LSE/scale        16 MFMA  (A: Q row fragments from LDS, B: K fragments pinned in VGPRs,
+                                                      C: the row constant as the INITIAL accumulator, read from LDS)
+      dP'[q,key] = dO V^T - Delta           16 MFMA  (A: dO row fragments, B: V row fragments, both from LDS)
+      P = exp2(c S'), dS = P dP'            VALU, 32 elements per lane; packed to 16 bit in the accumulator layout,
+                                            which IS the B operand layout of the two products below (no LDS trip)
+      dV^T[d,key] += dO^T P                 16 MFMA  (A: transposed LDS reads of the dO slice image)
+      dK^T[d,key] += Q^T dS                 16 MFMA  (A: transposed LDS reads of the Q slice image)
+  64 MFMAs per trip and SIMD = 2048 cycles of matrix pipe; everything else (80 LDS reads, 5 LDS-DMA pieces, ~150 VALU)
+  is placed into the gaps by tools/asmgen/sched.py.
+  Q / dO slices (and the 64 row constants) arrive by LDS-DMA three slices ahead into a 4-deep ring; one s_barrier per
+  trip; the wave's V rows sit in LDS for the whole workgroup, its K fragments in registers.
+
+LDS map (bytes):   [0, 1024)            row constants, 4 stages x (32 x -LSE/scale | 32 x -Delta) f32
+                   [1024, 66560)        4 stages x (Q slice image 8 KB | dO slice image 8 KB)
+                   [66560, 132096)      V image of the workgroup's 256 keys
+Slice / V images are the dual-use layout "8-row x 32-column subtiles" (conflict-free for row reads AND transposed
+reads, 2 + 2 address registers): off(row, ch) = 2048 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)).
+"""
+from __future__ import annotations
+
+from .core import A, Imm, Instr, M0, P, PV, Prog, Reg, S, V, VCC, fimm, imm
+from .sched import finish_block, fix_hazards, insert_waits, schedule
+
+CST_BASE = 0
+STG_BASE = 1024
+STG_BYTES = 16384
+V_BASE = STG_BASE + 4 * STG_BYTES          # 66560
+LDS_BYTES = V_BASE + 65536                 # 132096
+
+# scalar inputs of the asm statement ("s" operands), all 32 bit
+PARAMS = [
+    "q_lo", "q_hi", "do_lo", "do_hi", "c_lo", "c_hi", "k_lo", "k_hi", "v_lo", "v_hi", "dk_lo", "dk_hi", "dv_lo", "dv_hi",
+    "q_rng", "do_rng", "c_rng", "k_rng", "v_rng", "dk_rng", "dv_rng",
+    "q_sn", "do_sn", "k_sn", "v_sn", "dk_sn", "dv_sn",          # row strides, bytes
+    "q_hs", "do_hs", "c_hs",                                    # head strides, bytes
+    "nq", "g", "q_row0", "kb0", "pos0", "W", "ns", "nrows", "cdelta", "c_log2", "scale",
+]
+# q_*/do_*/c_* bases point at (first head of the group, the sequence's first row); q_row0 = first row of the first slice
+# the block sweeps; kb0 = first key of the block; pos0 = position of query row 0 among the keys (N_kv - N_q);
+# nrows = query rows of the sequence; cdelta = byte offset of the -Delta row of a head behind its -LSE/scale row.
+
+
+class Alloc:
+    def __init__(self, kind, lo, hi):
+        self.kind, self.next, self.hi = kind, lo, hi
+        self.names = {}
+
+    def __call__(self, name, n=1, align=1):
+        self.next = (self.next + align - 1) // align * align
+        r = Reg(self.kind, self.next, n)
+        self.next += n
+        assert self.next <= self.hi + 1, "out of %s registers at %s" % (self.kind, name)
+        self.names[name] = r
+        return r
+
+
+class DkdvGen:
+    def __init__(self, dtype="bf16", sched=True, vfirst=8, sfirst=56):
+        assert dtype in ("bf16", "f16")
+        self.dtype = dtype
+        self.do_sched = sched
+        self.va = Alloc("v", vfirst, 255)
+        self.sa = Alloc("s", sfirst, 99)      # s100 / s101 are reserved by the compiler
+        self.vfirst, self.sfirst = vfirst, sfirst
+        va, sa = self.va, self.sa
+        # ---------------- VGPRs
+        self.KF = [[va("kf%d_%d" % (kbi, ks), 4, 4) for ks in range(8)] for kbi in range(2)]
+        self.QROW = [va("qrow%d" % ks, 4, 4) for ks in range(8)]
+        self.POOL = [va("pool%d" % i, 4, 4) for i in range(8)]
+        self.SACC = [va("sacc%d" % kbi, 16, 4) for kbi in range(2)]
+        self.DPACC = [va("dpacc%d" % kbi, 16, 4) for kbi in range(2)]
+        self.PPK = [[va("ppk%d_%d" % (kbi, s), 4, 4) for s in range(2)] for kbi in range(2)]
+        self.lane = va("lane")
+        self.l_row_e = va("l_row_e")       # lane part of the row-read address (k-step even), slice / V images
+        self.l_tr0 = va("l_tr0")           # lane part of the transposed-read address (first 8-row half)
+        self.l_c = va("l_c")               # lane part of the row-constant read address (16 h)
+        self.a_row_e, self.a_row_o = va("a_row_e"), va("a_row_o")
+        self.a_rown_e, self.a_rown_o = va("a_rown_e"), va("a_rown_o")
+        self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
+        self.a_v_e, self.a_v_o = va("a_v_e"), va("a_v_o")
+        self.a_c = va("a_c")
+        self.vo_q = [va("vo_q0"), va("vo_q1")]
+        self.vo_d = [va("vo_d0"), va("vo_d1")]
+        self.vo_c, self.vo_ce = va("vo_c"), va("vo_ce")
+        self.v_oob = va("v_oob")           # a byte offset no descriptor covers
+        self.lane31 = va("lane31")
+        self.v_kh = va("v_kh")
+        self.v_weff = [va("v_weff0"), va("v_weff1")]
+        self.v_d = [va("v_d0"), va("v_d1")]
+        self.tmp = [va("tmp%d" % i) for i in range(4)]
+        self.vo_k = [va("vo_k0"), va("vo_k1")]      # prologue (K fragment loads) / epilogue (store offsets) scratch
+        # ---------------- AGPRs
+        self.DV = [[A((db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(4)]
+        self.DK = [[A(128 + (db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(4)]
+        # ---------------- SGPRs
+        self.d_q, self.d_do, self.d_c = sa("d_q", 4, 4), sa("d_do", 4, 4), sa("d_c", 4, 4)
+        self.d_x = sa("d_x", 4, 4)               # K / V / dK / dV descriptor (prologue, epilogue)
+        self.s_wave = sa("s_wave")
+        self.s_t, self.s_n = sa("s_t"), sa("s_n")
+        self.s_st, self.s_stn, self.s_std = sa("s_st"), sa("s_stn"), sa("s_std")
+        self.s_cst, self.s_cstd = sa("s_cst"), sa("s_cstd")
+        self.s_ldq, self.s_ldh, self.s_ldrow = sa("s_ldq"), sa("s_ldh"), sa("s_ldrow")
+        self.s_cq, self.s_q0p = sa("s_cq"), sa("s_q0p")
+        self.s_kw63, self.s_kww, self.s_allsink = sa("s_kw63"), sa("s_kww"), sa("s_allsink")
+        self.s_stepq, self.s_stepd = sa("s_stepq"), sa("s_stepd")     # 32 rows in bytes
+        self.s_spanq, self.s_spand, self.s_spanc = sa("s_spanq"), sa("s_spand"), sa("s_spanc")
+        self.s_wofs = sa("s_wofs")                # 2048 * wave: the wave's two DMA pieces inside a slice image
+        self.s_tmp = [sa("s_tmp%d" % i) for i in range(4)]
+        self.pool_next = 0
+
+    # ------------------------------------------------------------------ helpers
+    def pool(self):
+        r = self.POOL[self.pool_next % len(self.POOL)]
+        self.pool_next += 1
+        return r
+
+    # LDS-DMA of one slice (Q, dO, row constants) into ring stage s_std / s_cstd, with the running source offsets
+    def emit_dma_issue(self, p: Prog):
+        p.s_add_m0(self.s_std, self.s_wofs, note="Q piece 0 of this wave")
+        p.buffer_load_lds(16, self.vo_q[0], self.d_q, 0, mem=("dma_stage",))
+        p.s_add_m0(M0, 1024)
+        p.buffer_load_lds(16, self.vo_q[1], self.d_q, 0, mem=("dma_stage",))
+        p.s_add_m0(M0, 8192 - 1024, note="dO piece 0")
+        p.buffer_load_lds(16, self.vo_d[0], self.d_do, 0, mem=("dma_stage",))
+        p.s_add_m0(M0, 1024)
+        p.buffer_load_lds(16, self.vo_d[1], self.d_do, 0, mem=("dma_stage",))
+        # row constants: lanes 0..31 -LSE/scale, 32..63 -Delta of rows q0 .. q0+31; rows >= nrows are forced out of range
+        # (they read 0: p = exp2(0) stays finite against the zero Q / dO rows, nothing reaches dK / dV)
+        p.s_sub_i32(self.s_tmp[0], P("nrows"), self.s_ldrow, note="rows left in the sequence")
+        p.v_cmp("gt_i32", self.s_tmp[0], self.lane31)
+        p.v_cndmask(self.vo_ce, self.v_oob, self.vo_c)
+        p.s_mov_m0(self.s_cstd)
+        p.buffer_load_lds(4, self.vo_ce, self.d_c, 0, mem=("dma_stage",))
+
+    def emit_dma_step(self, p: Prog):
+        """advance the source offsets to the next slice of the same head"""
+        p.v_add_u32(self.vo_q[0], self.s_stepq, self.vo_q[0])
+        p.v_add_u32(self.vo_q[1], self.s_stepq, self.vo_q[1])
+        p.v_add_u32(self.vo_d[0], self.s_stepd, self.vo_d[0])
+        p.v_add_u32(self.vo_d[1], self.s_stepd, self.vo_d[1])
+        p.v_add_u32(self.vo_c, 128, self.vo_c)
+        p.s_add_u32(self.s_ldq, self.s_ldq, 1)
+        p.s_add_u32(self.s_ldrow, self.s_ldrow, 32)
+
+    def emit_dma_headcheck(self, p: Prog, uniq: str):
+        """the next slice to fetch starts a new q head: move the descriptors, rewind the offsets; past the last head
+        the descriptors get zero records (the remaining fetches of the pipeline then touch no memory)"""
+        lbl = "L_nohead_%s%%=" % uniq
+        p.s_cmp("lt_u32", self.s_ldq, P("nq"))
+        p.s_cbranch("scc1", lbl)
+        p.s_mov(self.s_ldq, 0)
+        p.s_mov(self.s_ldrow, P("q_row0"))
+        p.s_add_u32(self.s_ldh, self.s_ldh, 1)
+        for d, hs in ((self.d_q, "q_hs"), (self.d_do, "do_hs"), (self.d_c, "c_hs")):
+            p.s_add_u32(d[0], d[0], P(hs))
+            p.s_addc_u32(d[1], d[1], 0)
+        p.v_sub_u32(self.vo_q[0], self.vo_q[0], self.s_spanq)
+        p.v_sub_u32(self.vo_q[1], self.vo_q[1], self.s_spanq)
+        p.v_sub_u32(self.vo_d[0], self.vo_d[0], self.s_spand)
+        p.v_sub_u32(self.vo_d[1], self.vo_d[1], self.s_spand)
+        p.v_sub_u32(self.vo_c, self.vo_c, self.s_spanc)
+        p.s_cmp("lt_u32", self.s_ldh, P("g"))
+        p.s_cbranch("scc1", lbl)
+        p.s_mov(self.d_q[2], 0)
+        p.s_mov(self.d_do[2], 0)
+        p.s_mov(self.d_c[2], 0)
+        p.label(lbl)
+
+    def emit_qrow_prefetch(self, p: Prog, e, o):
+        for ks in range(8):
+            base = o if ks & 1 else e
+            p.ds_read_b128(self.QROW[ks], base, 512 * (ks >> 1), mem=("stage_r",), note="Q rows, k-step %d" % ks)
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self) -> Prog:
+        p = Prog()
+        t0, t1, t2, t3 = self.tmp
+        lane, wv = self.lane, self.s_wave
+        p.v_and(lane, 63, PV("tid"))
+        p.v_lshrrev(t0, 6, PV("tid"))
+        p.v_readfirstlane(wv, t0)
+        p.v_and(self.lane31, 31, lane)
+        # r = lane & 31, h = lane >> 5 ; l_row_e = 2048 (r >> 3) + 64 (r & 7) + 16 (h ^ ((r >> 2) & 3))
+        p.v_lshrrev(t0, 3, self.lane31)                       # r >> 3
+        p.v_lshlrev(t0, 11, t0)
+        p.v_and(t1, 7, lane)                                  # r & 7
+        p.v_lshl_add_u32(t0, t1, 6, t0)
+        p.v_bfe_u32(t1, lane, 2, 2)                           # (r >> 2) & 3
+        p.v_lshrrev(t2, 5, lane)                              # h
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(self.l_row_e, t1, 4, t0)
+        p.v_lshlrev(self.l_c, 4, t2)                          # 16 h
+        # l_tr0 = 64 (4 h + q4) + 16 ((2 g1 + (p4 >> 1)) ^ h) + 8 (p4 & 1);  q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1
+        p.v_bfe_u32(t0, lane, 2, 2)                           # q4
+        p.v_lshl_add_u32(t0, t2, 2, t0)                       # 4 h + q4
+        p.v_lshlrev(t0, 6, t0)
+        p.v_bfe_u32(t1, lane, 4, 1)                           # g1
+        p.v_bfe_u32(t3, lane, 1, 1)                           # p4 >> 1
+        p.v_lshl_add_u32(t1, t1, 1, t3)
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(t0, t1, 4, t0)
+        p.v_and(t1, 1, lane)
+        p.v_lshl_add_u32(self.l_tr0, t1, 3, t0)
+        # V image row-read addresses: V_BASE + 16384 wave + l_row_e
+        p.s_lshl_b32(self.s_tmp[0], wv, 14)
+        p.s_add_u32(self.s_tmp[0], self.s_tmp[0], V_BASE)
+        p.v_add_u32(self.a_v_e, self.s_tmp[0], self.l_row_e)
+        p.v_xor(self.a_v_o, 32, self.a_v_e)
+        p.s_lshl_b32(self.s_wofs, wv, 11)
+
+        # ---- descriptors of the three streamed tensors
+        for d, nm in ((self.d_q, "q"), (self.d_do, "do"), (self.d_c, "c")):
+            p.s_mov(d[0], P(nm + "_lo"))
+            p.s_mov(d[1], P(nm + "_hi"))
+            p.s_mov(d[2], P(nm + "_rng"))
+            p.s_mov(d[3], 0x00020000)
+
+        # ---- V image of this wave's 64 keys: 16 LDS-DMA pieces (8 row groups x 2 halves of 128 bytes)
+        p.s_mov(self.d_x[0], P("v_lo"))
+        p.s_mov(self.d_x[1], P("v_hi"))
+        p.s_mov(self.d_x[2], P("v_rng"))
+        p.s_mov(self.d_x[3], 0x00020000)
+        # lane pattern of a piece: rr = (lane >> 2) & 7, slot = lane & 3, cbl = lane >> 5
+        rr, slot = t0, t1
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.s_lshl_b32(self.s_tmp[0], wv, 6)
+        p.s_add_u32(self.s_tmp[0], self.s_tmp[0], P("kb0"))       # first key of the wave
+        p.s_mul_i32(self.s_tmp[1], self.s_tmp[0], P("v_sn"))      # its byte offset
+        p.v_mul_lo_u32(t2, rr, P("v_sn"))
+        p.v_add_u32(t2, self.s_tmp[1], t2)                        # row (wave key0 + rr) bytes
+        p.v_lshrrev(t3, 5, lane)
+        p.v_lshl_add_u32(t2, t3, 6, t2)                           # + 64 cbl
+        p.s_lshl_b32(self.s_tmp[2], wv, 14)
+        p.s_add_u32(self.s_tmp[2], self.s_tmp[2], V_BASE)         # LDS base of the wave's part
+        p.s_lshl_b32(self.s_tmp[3], P("v_sn"), 3)                 # 8 rows
+        for rgl in range(8):
+            # x = (2 rgl + (rr >> 2)) & 3 ; chunk-in-block = slot ^ x
+            p.v_lshrrev(t3, 2, rr)
+            p.v_add_u32(t3, 2 * rgl, t3)
+            p.v_and(t3, 3, t3)
+            p.v_xor(t3, t3, slot)
+            p.v_lshl_add_u32(self.vo_k[0], t3, 4, t2)
+            p.v_add_u32(self.vo_k[1], 128, self.vo_k[0])
+            p.s_add_m0(self.s_tmp[2], 2048 * rgl)
+            p.buffer_load_lds(16, self.vo_k[0], self.d_x, 0, mem=("v_img",))
+            p.s_add_m0(M0, 1024)
+            p.buffer_load_lds(16, self.vo_k[1], self.d_x, 0, mem=("v_img",))
+            if rgl < 7:
+                p.v_add_u32(t2, self.s_tmp[3], t2)
+
+        # ---- K fragments: lane (r, h) of key block kbi holds K[key][16 ks + 8 h ..+8)
+        p.s_mov(self.d_x[0], P("k_lo"))
+        p.s_mov(self.d_x[1], P("k_hi"))
+        p.s_mov(self.d_x[2], P("k_rng"))
+        p.s_mul_i32(self.s_tmp[1], self.s_tmp[0], P("k_sn"))
+        p.v_mul_lo_u32(t2, self.lane31, P("k_sn"))
+        p.v_add_u32(t2, self.s_tmp[1], t2)
+        p.v_lshrrev(t3, 5, lane)
+        p.v_lshl_add_u32(self.vo_k[0], t3, 4, t2)
+        p.s_lshl_b32(self.s_tmp[1], P("k_sn"), 5)
+        p.v_add_u32(self.vo_k[1], self.s_tmp[1], self.vo_k[0])
+        for kbi in range(2):
+            for ks in range(8):
+                p.buffer_load(self.KF[kbi][ks], self.vo_k[kbi], self.d_x, 0, offset=32 * ks)
+
+        # ---- mask constants: key0 = wave key0 + r ; v_kh = key0 - 4 h ; weff = key < ns ? 2^31 : W
+        p.v_add_u32(t2, self.s_tmp[0], self.lane31)           # key of block 0
+        p.v_lshrrev(t3, 5, lane)
+        p.v_lshlrev(t3, 2, t3)
+        p.v_sub_u32(self.v_kh, t2, t3)
+        p.v_mov(t3, P("W"))
+        p.v_mov(t0, imm(0x80000000))
+        p.v_cmp("le_u32", P("ns"), t2)                        # not a sink key
+        p.v_cndmask(self.v_weff[0], t0, t3)                   # (a literal next to VCC would be two constant-bus reads)
+        p.v_add_u32(t2, 32, t2)
+        p.v_cmp("le_u32", P("ns"), t2)
+        p.v_cndmask(self.v_weff[1], t0, t3)
+        p.v_mov(self.v_oob, imm(0x7FFFFFF0))
+        # wave-level classification constants
+        p.s_add_u32(self.s_kw63, self.s_tmp[0], 63)
+        p.s_add_u32(self.s_kww, self.s_tmp[0], P("W"))
+        p.s_cmp("lt_i32", self.s_kw63, P("ns"))
+        p.s_cselect(self.s_allsink, 1, 0)
+
+        # ---- slice stream: source offsets of this wave's pieces.  piece (2 wave + e): rows 8 wave + rr, 16-byte chunk
+        #      4 (2 e + cbl) + (slot ^ ((2 wave + (rr >> 2)) & 3))
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.v_lshrrev(t3, 2, rr)
+        p.s_lshl_b32(self.s_tmp[1], wv, 1)
+        p.v_add_u32(t3, self.s_tmp[1], t3)
+        p.v_and(t3, 3, t3)
+        p.v_xor(t3, t3, slot)                                 # chunk in block
+        p.v_lshrrev(t2, 5, lane)
+        p.v_lshl_add_u32(t3, t2, 2, t3)                       # + 4 cbl
+        p.v_lshlrev(t3, 4, t3)                                # bytes
+        p.s_lshl_b32(self.s_tmp[1], wv, 3)
+        p.s_add_u32(self.s_tmp[1], self.s_tmp[1], P("q_row0"))    # first row of the wave's pieces in slice 0
+        p.v_add_u32(t2, self.s_tmp[1], rr)                    # row
+        for vo, sn in ((self.vo_q, "q_sn"), (self.vo_d, "do_sn")):
+            p.v_mul_lo_u32(vo[0], t2, P(sn))
+            p.v_add_u32(vo[0], vo[0], t3)
+            p.v_add_u32(vo[1], 128, vo[0])
+        # row constants: lane L < 32 -> -LSE/scale of row q_row0 + L ; L >= 32 -> -Delta of row q_row0 + L - 32
+        p.v_add_u32(t2, P("q_row0"), self.lane31)
+        p.v_lshlrev(t2, 2, t2)
+        p.v_lshrrev(t3, 5, lane)
+        p.v_mul_lo_u32(t3, t3, P("cdelta"))
+        p.v_add_u32(self.vo_c, t2, t3)
+        p.s_lshl_b32(self.s_stepq, P("q_sn"), 5)
+        p.s_lshl_b32(self.s_stepd, P("do_sn"), 5)
+        p.s_mul_i32(self.s_spanq, self.s_stepq, P("nq"))
+        p.s_mul_i32(self.s_spand, self.s_stepd, P("nq"))
+        p.s_lshl_b32(self.s_spanc, P("nq"), 7)
+        p.s_mov(self.s_ldq, 0)
+        p.s_mov(self.s_ldh, 0)
+        p.s_mov(self.s_ldrow, P("q_row0"))
+        p.s_mul_i32(self.s_n, P("nq"), P("g"))
+        # no trips at all (a block no row can see): nothing to fetch
+        p.s_cmp("lg_u32", self.s_n, 0)
+        p.s_cbranch("scc1", "L_some%=")
+        p.s_mov(self.d_q[2], 0)
+        p.s_mov(self.d_do[2], 0)
+        p.s_mov(self.d_c[2], 0)
+        p.label("L_some%=")
+
+        # ---- accumulators
+        for i in range(256):
+            p.v_accvgpr_write(A(i), 0)
+
+        # ---- first three slices into stages 0, 1, 2
+        for j in range(3):
+            p.s_mov(self.s_std, STG_BASE + j * STG_BYTES)
+            p.s_mov(self.s_cstd, CST_BASE + j * 256)
+            self.emit_dma_headcheck(p, "pro%d" % j)
+            self.emit_dma_issue(p)
+            self.emit_dma_step(p)
+        p.s_waitcnt(vmcnt=10, note="V image, K fragments, slice 0 landed (slices 1, 2 in flight)")
+        p.s_barrier()
+        # Q rows of slice 0
+        p.v_add_u32(self.a_rown_e, STG_BASE, self.l_row_e)
+        p.v_xor(self.a_rown_o, 32, self.a_rown_e)
+        self.emit_qrow_prefetch(p, self.a_rown_e, self.a_rown_o)
+        p.s_mov(self.s_t, 0)
+        p.s_mov(self.s_cq, 0)
+        p.s_add_u32(self.s_q0p, P("q_row0"), P("pos0"))
+        return p
+
+    # ------------------------------------------------------------------ loop head (scalar, branchy)
+    def loop_top(self) -> Prog:
+        p = Prog()
+        p.label("L_top%=")
+        p.s_cmp("ge_u32", self.s_t, self.s_n)
+        p.s_cbranch("scc1", "L_done%=")
+        self.emit_dma_headcheck(p, "loop")
+        # ring stages of this trip: current t & 3, next (t + 1) & 3, DMA target (t + 3) & 3
+        t0, t1 = self.s_tmp[0], self.s_tmp[1]
+        p.s_and_b32(t0, self.s_t, 3)
+        p.s_lshl_b32(self.s_cst, t0, 8)
+        p.s_lshl_b32(t0, t0, 14)
+        p.s_add_u32(self.s_st, t0, STG_BASE)
+        p.s_add_u32(t0, self.s_t, 1)
+        p.s_and_b32(t0, t0, 3)
+        p.s_lshl_b32(t0, t0, 14)
+        p.s_add_u32(self.s_stn, t0, STG_BASE)
+        p.s_add_u32(t0, self.s_t, 3)
+        p.s_and_b32(t0, t0, 3)
+        p.s_lshl_b32(self.s_cstd, t0, 8)
+        p.s_lshl_b32(t0, t0, 14)
+        p.s_add_u32(self.s_std, t0, STG_BASE)
+        # compute side: first row position of the slice (q0 + pos0), new head -> back to the first slice
+        p.s_cmp("lt_u32", self.s_cq, P("nq"))
+        p.s_cbranch("scc1", "L_samehead%=")
+        p.s_mov(self.s_cq, 0)
+        p.s_add_u32(self.s_q0p, P("q_row0"), P("pos0"))
+        p.label("L_samehead%=")
+        # class of (the wave's 64 keys) x (32 rows): full <=> all keys causal for all rows and (all sinks or all inside
+        # every row's window): kw63 <= q0p and (kw63 < ns or kw0 + W > q0p + 31)
+        p.s_cmp("le_i32", self.s_kw63, self.s_q0p)
+        p.s_cselect(t0, 1, 0)
+        p.s_add_u32(t1, self.s_q0p, 31)
+        p.s_cmp("gt_i32", self.s_kww, t1)
+        p.s_cselect(t1, 1, 0)
+        p.s_or_b32(t1, t1, self.s_allsink)
+        p.s_and_b32(t0, t0, t1)
+        p.s_add_u32(self.s_t, self.s_t, 1)
+        p.s_add_u32(self.s_cq, self.s_cq, 1)
+        p.s_cmp("lg_u32", t0, 0)
+        p.s_waitcnt(vmcnt=5, note="slice t+1 landed (own pieces); slice t+2 may be in flight")
+        p.s_barrier()
+        p.s_waitcnt(lgkmcnt=0, note="Q rows of this slice (fetched at the end of the last trip)")
+        p.s_cbranch("scc0", "L_edge%=")
+        return p
+
+    # ------------------------------------------------------------------ one trip
+    def trip_body(self, edge: bool) -> Prog:
+        p = Prog()
+        dt = self.dtype
+        self.pool_next = 0
+        # stage-relative addresses of this trip
+        p.v_add_u32(self.a_row_e, self.s_st, self.l_row_e)
+        p.v_xor(self.a_row_o, 32, self.a_row_e)
+        p.v_add_u32(self.a_tr0, self.s_st, self.l_tr0)
+        p.v_xor(self.a_tr1, 32, self.a_tr0)
+        p.v_add_u32(self.a_c, self.s_cst, self.l_c)
+        p.v_add_u32(self.a_rown_e, self.s_stn, self.l_row_e)
+        p.v_xor(self.a_rown_o, 32, self.a_rown_e)
+        # row constants as the initial accumulators: registers 4 g4 .. +3 <- rows 8 g4 + 4 h + {0..3}
+        for kbi in range(2):
+            for g4 in range(4):
+                p.ds_read_b128(self.SACC[kbi][4 * g4:4 * g4 + 4], self.a_c, 32 * g4, mem=("stage_r",))
+        # fetch slice t + 3
+        self.emit_dma_issue(p)
+        self.emit_dma_step(p)
+        # ---- [A] S' = Q K^T - LSE/scale, key block after key block
+        for kbi in range(2):
+            for ks in range(8):
+                p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
+        # dP accumulators start from -Delta
+        for kbi in range(2):
+            for g4 in range(4):
+                p.ds_read_b128(self.DPACC[kbi][4 * g4:4 * g4 + 4], self.a_c, 128 + 32 * g4, mem=("stage_r",))
+        if edge:
+            p.v_sub_u32(self.v_d[0], self.s_q0p, self.v_kh, note="(q0 + pos0 + 4 h) - key")
+            p.v_sub_u32(self.v_d[1], self.v_d[0], 32)
+        # ---- P = exp2(c S') (+ mask), packed
+        for kbi in range(2):
+            for v in range(16):
+                x = self.SACC[kbi][v]
+                p.v_mul_f32(x, P("c_log2"), x)
+                p.v_exp_f32(x, x)
+                if edge:
+                    o = (v & 3) + 8 * (v >> 2)
+                    p.v_add_u32(self.tmp[0], o, self.v_d[kbi])
+                    p.v_cmp("lt_u32", self.tmp[0], self.v_weff[kbi])
+                    p.v_cndmask(x, 0, x)
+            for s in range(2):
+                for j in range(4):
+                    p.v_cvt_pk(dt, self.PPK[kbi][s][j], self.SACC[kbi][8 * s + 2 * j], self.SACC[kbi][8 * s + 2 * j + 1])
+        # ---- [B] dP' = dO V^T - Delta, k-step after k-step (dO row fragment shared by the two key blocks)
+        for ks in range(8):
+            base = self.a_row_o if ks & 1 else self.a_row_e
+            fa = self.pool()
+            p.ds_read_b128(fa, base, 8192 + 512 * (ks >> 1), mem=("stage_r",), note="dO rows, k-step %d" % ks)
+            for kbi in range(2):
+                vb = self.a_v_o if ks & 1 else self.a_v_e
+                fv = self.pool()
+                p.ds_read_b128(fv, vb, 8192 * kbi + 512 * (ks >> 1), mem=("v_img_r",), note="V rows")
+                p.mfma(dt, self.DPACC[kbi], fa, fv, self.DPACC[kbi], tag="dP")
+        # ---- dS = P dP', packed into the (now free) S registers: [kbi][4 s + j]
+        for kbi in range(2):
+            for v in range(16):
+                p.v_mul_f32(self.DPACC[kbi][v], self.SACC[kbi][v], self.DPACC[kbi][v])
+            for s in range(2):
+                for j in range(4):
+                    p.v_cvt_pk(dt, self.SACC[kbi][4 * s + j], self.DPACC[kbi][8 * s + 2 * j], self.DPACC[kbi][8 * s + 2 * j + 1])
+        # ---- [C] dV^T += dO^T P ; [D] dK^T += Q^T dS   (A operands: transposed reads, rows 16 s + 8 half + ..)
+        for which in ("dV", "dK"):
+            img = 8192 if which == "dV" else 0
+            for db in range(4):
+                for s in range(2):
+                    f = self.pool()
+                    p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, img + 2048 * (2 * s) + 512 * db, mem=("stage_r",))
+                    p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, img + 2048 * (2 * s + 1) + 512 * db, mem=("stage_r",))
+                    for kbi in range(2):
+                        if which == "dV":
+                            p.mfma(dt, self.DV[db][kbi], f, self.PPK[kbi][s], self.DV[db][kbi], tag="dV")
+                        else:
+                            p.mfma(dt, self.DK[db][kbi], f, self.SACC[kbi][4 * s:4 * s + 4], self.DK[db][kbi], tag="dK")
+        # Q rows of the next slice (stage t + 1, landed before this trip's barrier)
+        self.emit_qrow_prefetch(p, self.a_rown_e, self.a_rown_o)
+        p.s_add_u32(self.s_q0p, self.s_q0p, 32)
+        return p
+
+    # ------------------------------------------------------------------ epilogue
+    def epilogue(self) -> Prog:
+        p = Prog()
+        dt = self.dtype
+        t0, t1, t2, t3 = self.tmp
+        p.label("L_done%=")
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        # store offsets: key (block kbi) * row stride + 8 h bytes ; d = 32 db + 8 g4 + 4 h -> immediate 64 db + 16 g4
+        p.s_lshl_b32(self.s_tmp[0], self.s_wave, 6)
+        p.s_add_u32(self.s_tmp[0], self.s_tmp[0], P("kb0"))
+        p.v_add_u32(t2, self.s_tmp[0], self.lane31)
+        p.v_lshrrev(t3, 5, self.lane)
+        p.v_lshlrev(t3, 3, t3)
+        for which, acc in (("dk", self.DK), ("dv", self.DV)):
+            p.s_mov(self.d_x[0], P(which + "_lo"))
+            p.s_mov(self.d_x[1], P(which + "_hi"))
+            p.s_mov(self.d_x[2], P(which + "_rng"))
+            p.s_mov(self.d_x[3], 0x00020000)
+            p.v_mul_lo_u32(self.vo_k[0], t2, P(which + "_sn"))
+            p.v_add_u32(self.vo_k[0], self.vo_k[0], t3)
+            p.s_lshl_b32(self.s_tmp[1], P(which + "_sn"), 5)
+            p.v_add_u32(self.vo_k[1], self.s_tmp[1], self.vo_k[0])
+            for kbi in range(2):
+                for db in range(4):
+                    for g4 in range(4):
+                        regs = self.POOL[(db * 4 + g4) % 8]
+                        for e in range(4):
+                            p.v_accvgpr_read(regs[e], acc[db][kbi][4 * g4 + e])
+                        if which == "dk":
+                            for e in range(4):
+                                p.v_mul_f32(regs[e], P("scale"), regs[e])
+                        p.v_cvt_pk(dt, regs[0], regs[0], regs[1])
+                        p.v_cvt_pk(dt, regs[1], regs[2], regs[3])
+                        p.buffer_store(regs[0:2], self.vo_k[kbi], self.d_x, 0, offset=64 * db + 16 * g4)
+        p.s_waitcnt(vmcnt=0)
+        return p
+
+    # ------------------------------------------------------------------ whole program
+    def build(self):
+        items = []
+        items += finish_block(self.prologue().items)
+        items += insert_waits(self.loop_top().items)
+        for edge in (False, True):
+            body = self.trip_body(edge).items
+            if edge:
+                items.append(Instr("label", mods={"label": "L_edge%="}, kind="label", cost=0))
+            if self.do_sched:
+                body = schedule(body)
+            body = insert_waits(body, strict_tail=False)
+            body = fix_hazards(body, loop=True)
+            items += body
+            items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        items += finish_block(self.epilogue().items)
+        return items
+
+    def clobbers(self):
+        c = ["v%d" % i for i in range(self.vfirst, 256)] + ["a%d" % i for i in range(256)]
+        c += ["s%d" % i for i in range(self.sfirst, 100)] + ["vcc", "scc", "memory"]
+        return c

@@ -1,0 +1,93 @@
+"""Runs the generated dK/dV kernel body in the CPU emulator on torch tensors (TEST INFRASTRUCTURE).
+
+`dkdv_block_params` restates, in Python, the scalar prologue of the HIP shell around the asm statement
+(csrc/sfa_bwd_asm.hip: block -> slice range, base pointers, ranges); tests/test_asm_emu.py runs every key block of a
+small problem through the emulator and compares dK / dV with the oracle.
+"""
+from __future__ import annotations
+
+import math
+import struct
+
+import numpy as np
+import torch
+
+from . import dkdv as K
+from .emu import Memory, Workgroup
+
+
+def f32_bits(x: float) -> int:
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def to_u16(t: torch.Tensor) -> np.ndarray:
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def dkdv_block_params(N, Nk, D, Hq, Hkv, ns, window, kb):
+    """slice range of the 256-key block `kb` (the shell's arithmetic; query row i sits at key position i + Nk - N)"""
+    P = Nk - N
+    W = min(max(window, 0), Nk)
+    kb0 = kb * 256
+    kb1 = min(kb0 + 256, Nk)
+    if kb0 < ns:
+        i_hi = N
+    else:
+        i_hi = min(max(kb1 - 1 + W - P, 0), N)
+    qt_lo = max(kb0 - P, 0) // 32
+    qt_hi = max((i_hi + 31) // 32, qt_lo)
+    return dict(P=P, W=W, kb0=kb0, qt_lo=qt_lo, nq=qt_hi - qt_lo)
+
+
+def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, blocks=None, stats=None):
+    """q, do [B, Hq, N, D]; k, v [B, Hkv, Nk, D] (torch, bf16 / f16); lse, delta [B, Hq, N] float.
+    Returns dk, dv [B, Hkv, Nk, D] float32 (as stored by the kernel: 16-bit values)."""
+    B, Hq, N, D = q.shape
+    Hkv, Nk = k.shape[1], k.shape[2]
+    g = Hq // Hkv
+    assert D == 128
+    scale = 1.0 / math.sqrt(D)
+    mem = Memory()
+    aq, ak, av, ado = (mem.alloc(to_u16(t)) for t in (q, k, v, do))
+    consts = torch.stack([-(lse.double() / scale), -delta.double()], dim=2).float().contiguous()   # [B, Hq, 2, N]
+    ac = mem.alloc(consts.numpy())
+    adk = mem.alloc_zero(B * Hkv * Nk * D * 2)
+    adv = mem.alloc_zero(B * Hkv * Nk * D * 2)
+    nkb = (Nk + 255) // 256
+    for b in range(B):
+        for hk in range(Hkv):
+            for kb in range(nkb):
+                if blocks is not None and (b, hk, kb) not in blocks:
+                    continue
+                bp = dkdv_block_params(N, Nk, D, Hq, Hkv, ns, window, kb)
+                head0 = hk * g
+                qb = aq + ((b * Hq + head0) * N) * D * 2
+                dob = ado + ((b * Hq + head0) * N) * D * 2
+                cb = ac + ((b * Hq + head0) * 2 * N) * 4
+                kbp = ak + ((b * Hkv + hk) * Nk) * D * 2
+                vbp = av + ((b * Hkv + hk) * Nk) * D * 2
+                dkb = adk + ((b * Hkv + hk) * Nk) * D * 2
+                dvb = adv + ((b * Hkv + hk) * Nk) * D * 2
+                rng_q = ((N - 1) * D + D) * 2
+                rng_k = ((Nk - 1) * D + D) * 2
+                params = dict(
+                    q_lo=qb & 0xFFFFFFFF, q_hi=qb >> 32, do_lo=dob & 0xFFFFFFFF, do_hi=dob >> 32,
+                    c_lo=cb & 0xFFFFFFFF, c_hi=cb >> 32, k_lo=kbp & 0xFFFFFFFF, k_hi=kbp >> 32,
+                    v_lo=vbp & 0xFFFFFFFF, v_hi=vbp >> 32, dk_lo=dkb & 0xFFFFFFFF, dk_hi=dkb >> 32,
+                    dv_lo=dvb & 0xFFFFFFFF, dv_hi=dvb >> 32,
+                    q_rng=rng_q, do_rng=rng_q, c_rng=2 * N * 4, k_rng=rng_k, v_rng=rng_k, dk_rng=rng_k, dv_rng=rng_k,
+                    q_sn=D * 2, do_sn=D * 2, k_sn=D * 2, v_sn=D * 2, dk_sn=D * 2, dv_sn=D * 2,
+                    q_hs=N * D * 2, do_hs=N * D * 2, c_hs=2 * N * 4,
+                    nq=bp["nq"], g=g, q_row0=bp["qt_lo"] * 32, kb0=bp["kb0"], pos0=bp["P"], W=bp["W"], ns=ns, nrows=N,
+                    cdelta=N * 4, c_log2=f32_bits(scale * math.log2(math.e)), scale=f32_bits(scale))
+                assert set(params) == set(K.PARAMS), set(params) ^ set(K.PARAMS)
+                wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+                wg.run()
+                if stats is not None:
+                    stats.append({"block": (b, hk, kb), "nq": bp["nq"], "icount": [w.icount for w in wg.waves],
+                                  "kinds": dict(wg.waves[0].stats)})
+    def back(addr):
+        raw = mem.read(addr).view(np.uint16).reshape(B, Hkv, Nk, D)
+        t = torch.from_numpy(raw.view(np.int16).copy())
+        return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+    return back(adk), back(adv)

@@ -1,0 +1,326 @@
+"""Placement of a straight-line instruction list around its MFMA spine, plus the two passes every emitted block
+goes through: counted s_waitcnt insertion for LDS / global loads into registers, and gfx950 wait-state padding.
+
+schedule(items): the MFMAs keep their program order and pace the block (one per 32 cycles on a SIMD); every other
+instruction is a "filler" placed into the gaps between them, earliest program order first, as soon as the
+instructions it depends on have been placed (register RAW / WAR / WAW and declared LDS-region dependences are taken
+from the instruction objects, so any order the scheduler produces computes what the program order computes).
+Fences (barriers, hand-written waits, M0 / SCC / VCC chains through registers) are respected the same way.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+from .core import Imm, Instr, Prog, Reg
+
+MFMA_PIPE = 32      # cycles of the matrix pipe per v_mfma_f32_32x32x16
+MFMA_ISSUE = 8      # cycles the MFMA holds the wave's issue
+LDS_LAT = 128       # issue -> data, modelled (a wait is inserted wherever the consumer really sits)
+MFMA_LAT = 64       # issue -> result readable by a non-MFMA instruction, modelled
+VALU_LAT = 8
+
+
+def _is_fence(it: Instr) -> bool:
+    return it.kind in ("barrier", "label", "branch") or (it.kind == "wait")
+
+
+def build_deps(items: Sequence[Instr]) -> List[List[int]]:
+    """deps[i] = indices j < i that must be placed before i."""
+    n = len(items)
+    deps: List[set] = [set() for _ in range(n)]
+    last_w: Dict[object, int] = {}
+    readers: Dict[object, List[int]] = {}
+    last_fence = -1
+    since_fence: List[int] = []
+    last_mfma = -1
+    for i, it in enumerate(items):
+        if last_fence >= 0:
+            deps[i].add(last_fence)
+        rd = list(it.reads()) + [("mem", t) for t in it.mem_r]
+        wr = list(it.writes()) + [("mem", t) for t in it.mem_w]
+        for r in rd:
+            if r in last_w:
+                deps[i].add(last_w[r])
+        for r in wr:
+            if r in last_w:
+                deps[i].add(last_w[r])
+            for j in readers.get(r, ()):
+                if j != i:
+                    deps[i].add(j)
+        if it.kind == "mfma":
+            if last_mfma >= 0:
+                deps[i].add(last_mfma)          # the spine keeps its order
+            last_mfma = i
+        if _is_fence(it):
+            for j in since_fence:
+                deps[i].add(j)
+            last_fence = i
+            since_fence = []
+        else:
+            since_fence.append(i)
+        for r in rd:
+            readers.setdefault(r, []).append(i)
+        for r in wr:
+            last_w[r] = i
+            readers[r] = []
+        deps[i].discard(i)
+    return [sorted(d) for d in deps]
+
+
+def schedule(items: Sequence[Instr], gap_budget: int = 24, verbose: bool = False) -> List[Instr]:
+    """Reorder `items` (no labels / branches inside, fences allowed) around the MFMA spine."""
+    items = list(items)
+    n = len(items)
+    deps = build_deps(items)
+    users: List[List[int]] = [[] for _ in range(n)]
+    for i, d in enumerate(deps):
+        for j in d:
+            users[j].append(i)
+    placed_at = [-1.0] * n      # issue time
+    done = [False] * n
+    ndeps = [len(d) for d in deps]
+    ready = sorted(i for i in range(n) if ndeps[i] == 0)
+    out: List[int] = []
+    t = 0.0                     # wave issue clock
+    pipe_free = 0.0             # matrix pipe
+    remaining = n
+
+    def result_time(j: int) -> float:
+        it = items[j]
+        if it.kind == "ds_read":
+            return placed_at[j] + LDS_LAT
+        if it.kind == "mfma":
+            return placed_at[j] + MFMA_LAT
+        if it.kind == "trans":
+            return placed_at[j] + 16
+        if it.kind in ("vload",):
+            return placed_at[j] + 800
+        return placed_at[j] + VALU_LAT
+
+    def data_ready(i: int) -> float:
+        """time at which i's register inputs are there (true dependences only)"""
+        it = items[i]
+        rd = set(it.reads())
+        tt = 0.0
+        for j in deps[i]:
+            pj = items[j]
+            if rd & set(pj.writes()):
+                if it.kind == "mfma" and pj.kind == "mfma":
+                    tt = max(tt, placed_at[j] + (MFMA_PIPE if rd & set(pj.writes()) else 0))
+                else:
+                    tt = max(tt, result_time(j))
+        return tt
+
+    def place(i: int):
+        nonlocal t, pipe_free, remaining
+        it = items[i]
+        if it.kind == "mfma":
+            t = max(t, pipe_free)
+            placed_at[i] = t
+            pipe_free = t + MFMA_PIPE
+            t += MFMA_ISSUE
+        else:
+            placed_at[i] = t
+            t += it.cost
+        done[i] = True
+        out.append(i)
+        remaining -= 1
+        ready.remove(i)
+        for u in users[i]:
+            ndeps[u] -= 1
+            if ndeps[u] == 0:
+                ready.append(u)
+        ready.sort()
+
+    while remaining:
+        # next MFMA of the spine, if its dependences are placed
+        mf = next((i for i in ready if items[i].kind == "mfma"), None)
+        fillers = [i for i in ready if items[i].kind != "mfma"]
+        if mf is not None:
+            start = max(pipe_free, data_ready(mf))
+            # fill the time until the MFMA can start with fillers whose inputs are there; a fence is taken only when
+            # nothing else is left before it (it depends on everything since the last fence anyway)
+            placed_filler = False
+            for i in fillers:
+                if t + items[i].cost <= start + 0.5 or t + items[i].cost <= pipe_free + 0.5:
+                    if data_ready(i) <= t + 0.5:
+                        place(i)
+                        placed_filler = True
+                        break
+            if placed_filler:
+                continue
+            # nothing fits: would a not-yet-ready filler be the better use of the wait?  take the earliest-ready one
+            # if it becomes ready before the MFMA could start anyway
+            cand = [(data_ready(i), i) for i in fillers]
+            cand = [c for c in cand if c[0] + items[c[1]].cost <= start + 0.5]
+            if cand:
+                tr, i = min(cand)
+                t = max(t, tr)
+                place(i)
+                continue
+            t = max(t, start - 0.0)
+            place(mf)
+            continue
+        if not fillers:
+            raise RuntimeError("scheduler stuck: dependence cycle?")
+        # no MFMA placeable: take fillers in program order (the one whose data is ready first, ties by order)
+        cand = sorted((max(data_ready(i), t), i) for i in fillers)
+        tr, i = cand[0]
+        t = max(t, tr) if items[i].kind not in ("wait", "barrier") else t
+        place(i)
+    if verbose:
+        nm = sum(1 for i in out if items[i].kind == "mfma")
+        print("schedule: %d instructions, %d MFMA, modelled %.0f cycles (MFMA floor %d)" % (n, nm, max(t, pipe_free), nm * MFMA_PIPE))
+    return [items[i] for i in out]
+
+
+# ------------------------------------------------------------------ waits
+def insert_waits(items: Sequence[Instr], strict: bool = False, strict_tail: bool = False) -> List[Instr]:
+    """Insert counted s_waitcnt lgkmcnt(N) / vmcnt(N) in front of every instruction that touches a register with an
+    outstanding ds_read / buffer_load into it.  LDS ops complete in order, so do vector memory ops (loads, stores
+    and LDS-DMA share the vmcnt queue).  Hand-written waits in `items` are honoured (they shorten the queues).
+    Labels and branches: the bookkeeping restarts empty there (`strict`: register loads outstanding there are an error)."""
+    out: List[Instr] = []
+    lgkm: List[set] = []      # outstanding LDS ops, oldest first: set of destination registers (may be empty)
+    vm: List[set] = []
+    for it in items:
+        k = it.kind
+        if k in ("label", "branch"):
+            # control flow joins / leaves here: what is outstanding is the hand-written waits' business (the emulator
+            # checks them); the automatic bookkeeping restarts empty
+            if strict and (any(lgkm) or any(vm)):
+                raise RuntimeError("register load outstanding across %s: wait before it" % it.text())
+            lgkm, vm = [], []
+            out.append(it)
+            continue
+        if k == "wait":
+            m = it.mods
+            if "lgkmcnt" in m:
+                del lgkm[:max(0, len(lgkm) - m["lgkmcnt"])]
+            if "vmcnt" in m:
+                del vm[:max(0, len(vm) - m["vmcnt"])]
+            out.append(it)
+            continue
+        touched = set(it.reads()) | set(it.writes())
+        need_l = need_v = None
+        for pos, regs in enumerate(lgkm):
+            if regs & touched:
+                need_l = len(lgkm) - 1 - pos     # ops younger than this one may stay outstanding
+        for pos, regs in enumerate(vm):
+            if regs & touched:
+                need_v = len(vm) - 1 - pos
+        if need_l is not None or need_v is not None:
+            w = Instr("s_waitcnt", kind="wait", mods={})
+            if need_l is not None:
+                w.mods["lgkmcnt"] = min(need_l, 15)
+                del lgkm[:len(lgkm) - min(need_l, 15)]
+            if need_v is not None:
+                w.mods["vmcnt"] = min(need_v, 63)
+                del vm[:len(vm) - min(need_v, 63)]
+            out.append(w)
+        if k == "ds_read":
+            lgkm.append(set(it.writes()))
+        elif k == "ds_write":
+            lgkm.append(set())
+        elif k == "vload":
+            vm.append(set(it.writes()))
+        elif k in ("dma", "vstore"):
+            vm.append(set())
+        if len(lgkm) > 15:
+            # the counter saturates at 15: keep the model exact by waiting explicitly (rare: >15 reads in flight)
+            w = Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 15})
+            out.append(it)
+            out.append(w)
+            del lgkm[:len(lgkm) - 15]
+            continue
+        out.append(it)
+    return out
+
+
+# ------------------------------------------------------------------ hazards
+def _wait_states(it: Instr) -> int:
+    if it.kind == "nop":
+        return it.mods["n"] + 1
+    if it.kind == "label":
+        return 0
+    return 1
+
+
+def fix_hazards(items: Sequence[Instr], loop: bool = False) -> List[Instr]:
+    """Pad with s_nop where gfx950 needs software wait states and the stream does not provide them:
+        MFMA (8 pass) result  -> any non-MFMA access to those registers, or an MFMA reading them as A / B : 14 states
+                                 (as srcC of the next MFMA on the same registers: 0 ... accumulate chains are free)
+        VALU / LDS-return write -> MFMA A / B / C operand                                                  :  2
+        transcendental result   -> VALU use                                                               :  1
+        VALU write              -> v_permlane32_swap / v_readfirstlane of it                              :  2
+        SALU write of M0        -> LDS-DMA                                                                :  1
+        VALU write of an SGPR (v_readfirstlane) -> VMEM using it                                          :  5
+    `loop`: the list is a loop body, the tail feeds the head (checked by running over two copies)."""
+    def pass_once(seq: List[Instr], carry_in) -> (List[Instr], list):
+        out: List[Instr] = []
+        # recent history: list of (instr, states_since)
+        hist: List[list] = [list(h) for h in carry_in]
+
+        def need(it: Instr) -> int:
+            req = 0
+            rd, wr = set(it.reads()), set(it.writes())
+            for prev, since in hist:
+                pw = set(prev.writes())
+                if prev.kind == "mfma":
+                    hit_rw = pw & (rd | wr)
+                    if hit_rw:
+                        if it.kind == "mfma":
+                            # same registers taken whole as srcC (accumulate): free; as A/B operand or partial: hazard
+                            c = it.src[2]
+                            ab = set(it.src[0].regs()) | set(it.src[1].regs())
+                            if pw & ab:
+                                req = max(req, 14 - since)
+                            elif isinstance(c, Reg) and set(c.regs()) == pw and set(it.dst[0].regs()) == pw:
+                                pass
+                            else:
+                                req = max(req, 14 - since)
+                        else:
+                            req = max(req, 14 - since)
+                elif prev.kind in ("valu", "trans"):
+                    if it.kind == "mfma" and pw & rd:
+                        req = max(req, 2 - since)
+                    if prev.kind == "trans" and it.kind in ("valu", "trans", "mfma") and pw & rd:
+                        req = max(req, 1 - since)
+                    if it.op in ("v_permlane32_swap_b32", "v_readfirstlane_b32") and pw & rd:
+                        req = max(req, 2 - since)
+                    if prev.op == "v_readfirstlane_b32" and it.kind in ("dma", "vload", "vstore") and pw & rd:
+                        req = max(req, 5 - since)
+                elif prev.kind == "salu":
+                    if ("m0", 0) in pw and it.kind == "dma":
+                        req = max(req, 1 - since)
+            return req
+
+        for it in seq:
+            if it.kind != "label":
+                r = need(it)
+                while r > 0:
+                    n = min(r, 8)
+                    nop = Instr("s_nop", mods={"n": n - 1}, kind="nop", cost=4 * n, note="hazard pad")
+                    out.append(nop)
+                    for h in hist:
+                        h[1] += n
+                    r -= n
+            out.append(it)
+            ws = _wait_states(it)
+            for h in hist:
+                h[1] += ws
+            hist = [h for h in hist if h[1] < 16]
+            if it.kind in ("mfma", "valu", "trans", "salu"):
+                hist.append([it, 0])
+        return out, hist
+
+    seq = list(items)
+    out, hist = pass_once(seq, [])
+    if loop:
+        out, _ = pass_once(seq, hist)
+    return out
+
+
+def finish_block(items: Sequence[Instr], loop: bool = False) -> List[Instr]:
+    """waits + hazard padding for a block whose order is final"""
+    return fix_hazards(insert_waits(items), loop=loop)
