@@ -87,7 +87,7 @@ class DkdvGen:
         self.a_rown_e, self.a_rown_o = va("a_rown_e"), va("a_rown_o")
         self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
         self.a_v_e, self.a_v_o = va("a_v_e"), va("a_v_o")
-        self.a_c = va("a_c")
+        self.a_c, self.a_cn = va("a_c"), va("a_cn")
         self.vo_q = [va("vo_q0"), va("vo_q1")]
         self.vo_d = [va("vo_d0"), va("vo_d1")]
         self.vo_c, self.vo_ce = va("vo_c"), va("vo_ce")
@@ -107,7 +107,8 @@ class DkdvGen:
         self.s_wave = sa("s_wave")
         self.s_t, self.s_n = sa("s_t"), sa("s_n")
         self.s_st, self.s_stn, self.s_std = sa("s_st"), sa("s_stn"), sa("s_std")
-        self.s_cst, self.s_cstd = sa("s_cst"), sa("s_cstd")
+        self.s_cst, self.s_cstn, self.s_cstd = sa("s_cst"), sa("s_cstn"), sa("s_cstd")
+        self.s_full = sa("s_full")
         self.s_ldq, self.s_ldh, self.s_ldrow = sa("s_ldq"), sa("s_ldh"), sa("s_ldrow")
         self.s_cq, self.s_q0p = sa("s_cq"), sa("s_q0p")
         self.s_kw63, self.s_kww, self.s_allsink = sa("s_kw63"), sa("s_kww"), sa("s_allsink")
@@ -124,22 +125,25 @@ class DkdvGen:
         return r
 
     # LDS-DMA of one slice (Q, dO, row constants) into ring stage s_std / s_cstd, with the running source offsets
-    def emit_dma_issue(self, p: Prog):
+    def emit_dma_issue(self, p: Prog, spread: bool = False):
+        """`spread`: inside a trip the five pieces get early, staggered deadlines (one per ~4 MFMAs of the S chains, where
+        the gaps carry little else), so that the fetch is three trips ahead of its use in time as well"""
+        dl = (lambda i: {"alap": 40 + 130 * i}) if spread else (lambda i: {})
         p.s_add_m0(self.s_std, self.s_wofs, note="Q piece 0 of this wave")
-        p.buffer_load_lds(16, self.vo_q[0], self.d_q, 0, mem=("dma_stage",))
+        p.buffer_load_lds(16, self.vo_q[0], self.d_q, 0, mem=("dma_stage",)).mods.update(dl(0))
         p.s_add_m0(M0, 1024)
-        p.buffer_load_lds(16, self.vo_q[1], self.d_q, 0, mem=("dma_stage",))
+        p.buffer_load_lds(16, self.vo_q[1], self.d_q, 0, mem=("dma_stage",)).mods.update(dl(1))
         p.s_add_m0(M0, 8192 - 1024, note="dO piece 0")
-        p.buffer_load_lds(16, self.vo_d[0], self.d_do, 0, mem=("dma_stage",))
+        p.buffer_load_lds(16, self.vo_d[0], self.d_do, 0, mem=("dma_stage",)).mods.update(dl(2))
         p.s_add_m0(M0, 1024)
-        p.buffer_load_lds(16, self.vo_d[1], self.d_do, 0, mem=("dma_stage",))
+        p.buffer_load_lds(16, self.vo_d[1], self.d_do, 0, mem=("dma_stage",)).mods.update(dl(3))
         # row constants: lanes 0..31 -LSE/scale, 32..63 -Delta of rows q0 .. q0+31; rows >= nrows are forced out of range
         # (they read 0: p = exp2(0) stays finite against the zero Q / dO rows, nothing reaches dK / dV)
         p.s_sub_i32(self.s_tmp[0], P("nrows"), self.s_ldrow, note="rows left in the sequence")
         p.v_cmp("gt_i32", self.s_tmp[0], self.lane31)
         p.v_cndmask(self.vo_ce, self.v_oob, self.vo_c)
         p.s_mov_m0(self.s_cstd)
-        p.buffer_load_lds(4, self.vo_ce, self.d_c, 0, mem=("dma_stage",))
+        p.buffer_load_lds(4, self.vo_ce, self.d_c, 0, mem=("dma_stage",)).mods.update(dl(4))
 
     def emit_dma_step(self, p: Prog):
         """advance the source offsets to the next slice of the same head"""
@@ -151,12 +155,9 @@ class DkdvGen:
         p.s_add_u32(self.s_ldq, self.s_ldq, 1)
         p.s_add_u32(self.s_ldrow, self.s_ldrow, 32)
 
-    def emit_dma_headcheck(self, p: Prog, uniq: str):
+    def emit_dma_headchange(self, p: Prog, lbl_done: str):
         """the next slice to fetch starts a new q head: move the descriptors, rewind the offsets; past the last head
         the descriptors get zero records (the remaining fetches of the pipeline then touch no memory)"""
-        lbl = "L_nohead_%s%%=" % uniq
-        p.s_cmp("lt_u32", self.s_ldq, P("nq"))
-        p.s_cbranch("scc1", lbl)
         p.s_mov(self.s_ldq, 0)
         p.s_mov(self.s_ldrow, P("q_row0"))
         p.s_add_u32(self.s_ldh, self.s_ldh, 1)
@@ -169,11 +170,36 @@ class DkdvGen:
         p.v_sub_u32(self.vo_d[1], self.vo_d[1], self.s_spand)
         p.v_sub_u32(self.vo_c, self.vo_c, self.s_spanc)
         p.s_cmp("lt_u32", self.s_ldh, P("g"))
-        p.s_cbranch("scc1", lbl)
+        p.s_cbranch("scc1", lbl_done)
         p.s_mov(self.d_q[2], 0)
         p.s_mov(self.d_do[2], 0)
         p.s_mov(self.d_c[2], 0)
+
+    def emit_dma_headcheck(self, p: Prog, uniq: str):
+        lbl = "L_nohead_%s%%=" % uniq
+        p.s_cmp("lt_u32", self.s_ldq, P("nq"))
+        p.s_cbranch("scc1", lbl)
+        self.emit_dma_headchange(p, lbl)
         p.label(lbl)
+
+    def emit_class(self, p: Prog):
+        """s_full = class of (the wave's 64 keys) x (the 32 rows at s_q0p): 1 <=> every key is causal for every row and
+        (all keys are sinks or all are inside every row's window): kw63 <= q0p and (kw63 < ns or kw0 + W > q0p + 31)"""
+        t0, t1 = self.s_tmp[1], self.s_tmp[2]
+        p.s_cmp("le_i32", self.s_kw63, self.s_q0p)
+        p.s_cselect(t0, 1, 0)
+        p.s_add_u32(t1, self.s_q0p, 31)
+        p.s_cmp("gt_i32", self.s_kww, t1)
+        p.s_cselect(t1, 1, 0)
+        p.s_or_b32(t1, t1, self.s_allsink)
+        p.s_and_b32(self.s_full, t0, t1)
+
+    def emit_next_prefetch(self, p: Prog):
+        """operands of the next trip's S chains: Q row fragments and the -LSE/scale rows as initial accumulators"""
+        self.emit_qrow_prefetch(p, self.a_rown_e, self.a_rown_o)
+        for kbi in range(2):
+            for g4 in range(4):
+                p.ds_read_b128(self.SACC[kbi][4 * g4:4 * g4 + 4], self.a_cn, 32 * g4, mem=("stage_r",))
 
     def emit_qrow_prefetch(self, p: Prog, e, o):
         for ks in range(8):
@@ -347,59 +373,53 @@ class DkdvGen:
             self.emit_dma_step(p)
         p.s_waitcnt(vmcnt=10, note="V image, K fragments, slice 0 landed (slices 1, 2 in flight)")
         p.s_barrier()
-        # Q rows of slice 0
+        # operands of the first trip
         p.v_add_u32(self.a_rown_e, STG_BASE, self.l_row_e)
         p.v_xor(self.a_rown_o, 32, self.a_rown_e)
-        self.emit_qrow_prefetch(p, self.a_rown_e, self.a_rown_o)
+        p.v_add_u32(self.a_cn, CST_BASE, self.l_c)
+        self.emit_next_prefetch(p)
         p.s_mov(self.s_t, 0)
         p.s_mov(self.s_cq, 0)
         p.s_add_u32(self.s_q0p, P("q_row0"), P("pos0"))
+        self.emit_class(p)
+        p.s_mov(self.s_st, STG_BASE)
+        p.s_mov(self.s_stn, STG_BASE + STG_BYTES)
+        p.s_mov(self.s_std, STG_BASE + 3 * STG_BYTES)
+        p.s_mov(self.s_cst, CST_BASE)
+        p.s_mov(self.s_cstn, CST_BASE + 256)
+        p.s_mov(self.s_cstd, CST_BASE + 768)
         return p
 
     # ------------------------------------------------------------------ loop head (scalar, branchy)
     def loop_top(self) -> Prog:
+        """common path: 8 scalar instructions + the trip's wait / barrier; the two head changes are out of line"""
         p = Prog()
         p.label("L_top%=")
         p.s_cmp("ge_u32", self.s_t, self.s_n)
         p.s_cbranch("scc1", "L_done%=")
-        self.emit_dma_headcheck(p, "loop")
-        # ring stages of this trip: current t & 3, next (t + 1) & 3, DMA target (t + 3) & 3
-        t0, t1 = self.s_tmp[0], self.s_tmp[1]
-        p.s_and_b32(t0, self.s_t, 3)
-        p.s_lshl_b32(self.s_cst, t0, 8)
-        p.s_lshl_b32(t0, t0, 14)
-        p.s_add_u32(self.s_st, t0, STG_BASE)
-        p.s_add_u32(t0, self.s_t, 1)
-        p.s_and_b32(t0, t0, 3)
-        p.s_lshl_b32(t0, t0, 14)
-        p.s_add_u32(self.s_stn, t0, STG_BASE)
-        p.s_add_u32(t0, self.s_t, 3)
-        p.s_and_b32(t0, t0, 3)
-        p.s_lshl_b32(self.s_cstd, t0, 8)
-        p.s_lshl_b32(t0, t0, 14)
-        p.s_add_u32(self.s_std, t0, STG_BASE)
-        # compute side: first row position of the slice (q0 + pos0), new head -> back to the first slice
+        p.s_cmp("lt_u32", self.s_ldq, P("nq"))
+        p.s_cbranch("scc0", "L_dmahead%=")
+        p.label("L_top_a%=")
         p.s_cmp("lt_u32", self.s_cq, P("nq"))
-        p.s_cbranch("scc1", "L_samehead%=")
-        p.s_mov(self.s_cq, 0)
-        p.s_add_u32(self.s_q0p, P("q_row0"), P("pos0"))
-        p.label("L_samehead%=")
-        # class of (the wave's 64 keys) x (32 rows): full <=> all keys causal for all rows and (all sinks or all inside
-        # every row's window): kw63 <= q0p and (kw63 < ns or kw0 + W > q0p + 31)
-        p.s_cmp("le_i32", self.s_kw63, self.s_q0p)
-        p.s_cselect(t0, 1, 0)
-        p.s_add_u32(t1, self.s_q0p, 31)
-        p.s_cmp("gt_i32", self.s_kww, t1)
-        p.s_cselect(t1, 1, 0)
-        p.s_or_b32(t1, t1, self.s_allsink)
-        p.s_and_b32(t0, t0, t1)
-        p.s_add_u32(self.s_t, self.s_t, 1)
-        p.s_add_u32(self.s_cq, self.s_cq, 1)
-        p.s_cmp("lg_u32", t0, 0)
+        p.s_cbranch("scc0", "L_cmphead%=")
+        p.label("L_top_b%=")
+        p.s_cmp("lg_u32", self.s_full, 0)
         p.s_waitcnt(vmcnt=5, note="slice t+1 landed (own pieces); slice t+2 may be in flight")
         p.s_barrier()
-        p.s_waitcnt(lgkmcnt=0, note="Q rows of this slice (fetched at the end of the last trip)")
+        p.s_waitcnt(lgkmcnt=0, note="S-chain operands of this slice (fetched at the end of the last trip)")
         p.s_cbranch("scc0", "L_edge%=")
+        return p
+
+    def out_of_line(self) -> Prog:
+        p = Prog()
+        p.label("L_dmahead%=")
+        self.emit_dma_headchange(p, "L_top_a%=")
+        p.s_branch("L_top_a%=")
+        p.label("L_cmphead%=")
+        p.s_mov(self.s_cq, 0)
+        p.s_add_u32(self.s_q0p, P("q_row0"), P("pos0"))
+        self.emit_class(p)
+        p.s_branch("L_top_b%=")
         return p
 
     # ------------------------------------------------------------------ one trip
@@ -415,21 +435,19 @@ class DkdvGen:
         p.v_add_u32(self.a_c, self.s_cst, self.l_c)
         p.v_add_u32(self.a_rown_e, self.s_stn, self.l_row_e)
         p.v_xor(self.a_rown_o, 32, self.a_rown_e)
-        # row constants as the initial accumulators: registers 4 g4 .. +3 <- rows 8 g4 + 4 h + {0..3}
-        for kbi in range(2):
-            for g4 in range(4):
-                p.ds_read_b128(self.SACC[kbi][4 * g4:4 * g4 + 4], self.a_c, 32 * g4, mem=("stage_r",))
-        # fetch slice t + 3
-        self.emit_dma_issue(p)
-        self.emit_dma_step(p)
-        # ---- [A] S' = Q K^T - LSE/scale, key block after key block
-        for kbi in range(2):
-            for ks in range(8):
-                p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
-        # dP accumulators start from -Delta
+        p.v_add_u32(self.a_cn, self.s_cstn, self.l_c)
+        # dP accumulators start from -Delta: registers 4 g4 .. +3 <- rows 8 g4 + 4 h + {0..3}
         for kbi in range(2):
             for g4 in range(4):
                 p.ds_read_b128(self.DPACC[kbi][4 * g4:4 * g4 + 4], self.a_c, 128 + 32 * g4, mem=("stage_r",))
+        # fetch slice t + 3
+        self.emit_dma_issue(p, spread=True)
+        self.emit_dma_step(p)
+        # ---- [A] S' = Q K^T - LSE/scale, key block after key block (operands and initial accumulators were fetched
+        #      at the end of the previous trip)
+        for kbi in range(2):
+            for ks in range(8):
+                p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
         if edge:
             p.v_sub_u32(self.v_d[0], self.s_q0p, self.v_kh, note="(q0 + pos0 + 4 h) - key")
             p.v_sub_u32(self.v_d[1], self.v_d[0], 32)
@@ -457,13 +475,14 @@ class DkdvGen:
                 fv = self.pool()
                 p.ds_read_b128(fv, vb, 8192 * kbi + 512 * (ks >> 1), mem=("v_img_r",), note="V rows")
                 p.mfma(dt, self.DPACC[kbi], fa, fv, self.DPACC[kbi], tag="dP")
-        # ---- dS = P dP', packed into the (now free) S registers: [kbi][4 s + j]
+        # ---- dS = P dP', packed IN PLACE into dP registers [kbi][4 s + j] (the S registers are free from here on: the
+        #      next trip's initial accumulators go there while this trip's last MFMAs run)
         for kbi in range(2):
             for v in range(16):
                 p.v_mul_f32(self.DPACC[kbi][v], self.SACC[kbi][v], self.DPACC[kbi][v])
             for s in range(2):
                 for j in range(4):
-                    p.v_cvt_pk(dt, self.SACC[kbi][4 * s + j], self.DPACC[kbi][8 * s + 2 * j], self.DPACC[kbi][8 * s + 2 * j + 1])
+                    p.v_cvt_pk(dt, self.DPACC[kbi][4 * s + j], self.DPACC[kbi][8 * s + 2 * j], self.DPACC[kbi][8 * s + 2 * j + 1])
         # ---- [C] dV^T += dO^T P ; [D] dK^T += Q^T dS   (A operands: transposed reads, rows 16 s + 8 half + ..)
         for which in ("dV", "dK"):
             img = 8192 if which == "dV" else 0
@@ -476,10 +495,27 @@ class DkdvGen:
                         if which == "dV":
                             p.mfma(dt, self.DV[db][kbi], f, self.PPK[kbi][s], self.DV[db][kbi], tag="dV")
                         else:
-                            p.mfma(dt, self.DK[db][kbi], f, self.SACC[kbi][4 * s:4 * s + 4], self.DK[db][kbi], tag="dK")
-        # Q rows of the next slice (stage t + 1, landed before this trip's barrier)
-        self.emit_qrow_prefetch(p, self.a_rown_e, self.a_rown_o)
+                            p.mfma(dt, self.DK[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DK[db][kbi], tag="dK")
+        # operands of the next trip (stage t + 1, landed before this trip's barrier)
+        self.emit_next_prefetch(p)
+        # scalar state of the next trip (its class assumes the same q head; a head change redoes it out of line)
         p.s_add_u32(self.s_q0p, self.s_q0p, 32)
+        p.s_add_u32(self.s_t, self.s_t, 1)
+        p.s_add_u32(self.s_cq, self.s_cq, 1)
+        self.emit_class(p)
+        t0 = self.s_tmp[3]
+        p.s_mov(self.s_st, self.s_stn)
+        p.s_add_u32(t0, self.s_stn, STG_BYTES - STG_BASE)
+        p.s_and_b32(t0, t0, 0xFFFF)
+        p.s_add_u32(self.s_stn, t0, STG_BASE)
+        p.s_add_u32(t0, self.s_std, STG_BYTES - STG_BASE)
+        p.s_and_b32(t0, t0, 0xFFFF)
+        p.s_add_u32(self.s_std, t0, STG_BASE)
+        p.s_mov(self.s_cst, self.s_cstn)
+        p.s_add_u32(t0, self.s_cstn, 256)
+        p.s_and_b32(self.s_cstn, t0, 1023)
+        p.s_add_u32(t0, self.s_cstd, 256)
+        p.s_and_b32(self.s_cstd, t0, 1023)
         return p
 
     # ------------------------------------------------------------------ epilogue
@@ -534,6 +570,7 @@ class DkdvGen:
             body = fix_hazards(body, loop=True)
             items += body
             items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        items += finish_block(self.out_of_line().items)
         items += finish_block(self.epilogue().items)
         return items
 

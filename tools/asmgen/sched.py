@@ -67,8 +67,32 @@ def build_deps(items: Sequence[Instr]) -> List[List[int]]:
     return [sorted(d) for d in deps]
 
 
-def schedule(items: Sequence[Instr], gap_budget: int = 24, verbose: bool = False) -> List[Instr]:
-    """Reorder `items` (no labels / branches inside, fences allowed) around the MFMA spine."""
+def _latency(pj: Instr, it: Instr, true_dep: bool) -> float:
+    """cycles from the issue of pj to the earliest issue of the dependent `it`"""
+    if not true_dep:
+        return 0.0 if pj.kind != "mfma" else 4.0
+    if pj.kind == "ds_read":
+        return LDS_LAT
+    if pj.kind == "mfma":
+        return MFMA_PIPE if it.kind == "mfma" else MFMA_LAT
+    if pj.kind == "trans":
+        return 16.0
+    if pj.kind == "vload":
+        return 800.0
+    if pj.kind in ("salu",):
+        return 4.0 if it.kind != "dma" else 8.0
+    return VALU_LAT
+
+
+def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[Instr]:
+    """Reorder `items` (no labels / branches inside, fences allowed) around the MFMA spine.
+
+    List scheduling on a cycle model (MFMA: 8 cycles of issue, 32 of matrix pipe; fillers: their issue cost) with
+    as-late-as-possible deadlines as priorities: the k-th MFMA should start at 32 k; every other instruction gets the
+    latest issue time that still lets everything depending on it meet that (LDS latency 128, MFMA result 64, ...).
+    In every gap the ready instruction with the earliest deadline goes first; one that does not fit into the gap is
+    placed anyway when the next MFMA's ideal start is past its deadline (it would stall that or a later MFMA),
+    otherwise the MFMA goes.  `mods["alap"]` overrides a deadline (LDS-DMA: early in the block, see the kernels)."""
     items = list(items)
     n = len(items)
     deps = build_deps(items)
@@ -76,101 +100,93 @@ def schedule(items: Sequence[Instr], gap_budget: int = 24, verbose: bool = False
     for i, d in enumerate(deps):
         for j in d:
             users[j].append(i)
-    placed_at = [-1.0] * n      # issue time
-    done = [False] * n
-    ndeps = [len(d) for d in deps]
-    ready = sorted(i for i in range(n) if ndeps[i] == 0)
-    out: List[int] = []
-    t = 0.0                     # wave issue clock
-    pipe_free = 0.0             # matrix pipe
-    remaining = n
+    spine = [i for i in range(n) if items[i].kind == "mfma"]
+    rank = {i: k for k, i in enumerate(spine)}
+    t_end = MFMA_PIPE * len(spine)
+    wsets = [set(it.writes()) for it in items]
+    rsets = [set(it.reads()) for it in items]
 
-    def result_time(j: int) -> float:
-        it = items[j]
-        if it.kind == "ds_read":
-            return placed_at[j] + LDS_LAT
+    def lat(j: int, i: int) -> float:
+        return _latency(items[j], items[i], bool(wsets[j] & rsets[i]))
+
+    # ---- deadlines (backward over program order: every user has a larger index)
+    alap = [0.0] * n
+    for i in range(n - 1, -1, -1):
+        it = items[i]
+        cost = MFMA_ISSUE if it.kind == "mfma" else it.cost
+        a = float(t_end) - cost
+        for u in users[i]:
+            a = min(a, alap[u] - max(lat(i, u), cost))
         if it.kind == "mfma":
-            return placed_at[j] + MFMA_LAT
-        if it.kind == "trans":
-            return placed_at[j] + 16
-        if it.kind in ("vload",):
-            return placed_at[j] + 800
-        return placed_at[j] + VALU_LAT
+            a = min(a, float(MFMA_PIPE * rank[i]))
+        if "alap" in it.mods:
+            a = min(a, float(it.mods["alap"]))
+        alap[i] = a
+
+    placed_at = [-1.0] * n
+    ndeps = [len(d) for d in deps]
+    ready = set(i for i in range(n) if ndeps[i] == 0)
+    out: List[int] = []
+    t = 0.0
+    pipe_free = 0.0
+    next_spine = 0
 
     def data_ready(i: int) -> float:
-        """time at which i's register inputs are there (true dependences only)"""
-        it = items[i]
-        rd = set(it.reads())
         tt = 0.0
         for j in deps[i]:
-            pj = items[j]
-            if rd & set(pj.writes()):
-                if it.kind == "mfma" and pj.kind == "mfma":
-                    tt = max(tt, placed_at[j] + (MFMA_PIPE if rd & set(pj.writes()) else 0))
-                else:
-                    tt = max(tt, result_time(j))
+            tt = max(tt, placed_at[j] + lat(j, i))
         return tt
 
-    def place(i: int):
-        nonlocal t, pipe_free, remaining
+    def place(i: int, at: float):
+        nonlocal t, pipe_free, next_spine
         it = items[i]
+        placed_at[i] = at
         if it.kind == "mfma":
-            t = max(t, pipe_free)
-            placed_at[i] = t
-            pipe_free = t + MFMA_PIPE
-            t += MFMA_ISSUE
+            pipe_free = at + MFMA_PIPE
+            t = at + MFMA_ISSUE
+            next_spine += 1
         else:
-            placed_at[i] = t
-            t += it.cost
-        done[i] = True
+            t = at + it.cost
         out.append(i)
-        remaining -= 1
-        ready.remove(i)
+        ready.discard(i)
         for u in users[i]:
             ndeps[u] -= 1
             if ndeps[u] == 0:
-                ready.append(u)
-        ready.sort()
+                ready.add(u)
+        if trace is not None:
+            trace.append((at, it, alap[i]))
 
-    while remaining:
-        # next MFMA of the spine, if its dependences are placed
-        mf = next((i for i in ready if items[i].kind == "mfma"), None)
+    while len(out) < n:
+        mf = spine[next_spine] if next_spine < len(spine) and spine[next_spine] in ready else None
         fillers = [i for i in ready if items[i].kind != "mfma"]
         if mf is not None:
-            start = max(pipe_free, data_ready(mf))
-            # fill the time until the MFMA can start with fillers whose inputs are there; a fence is taken only when
-            # nothing else is left before it (it depends on everything since the last fence anyway)
-            placed_filler = False
+            start = max(pipe_free, data_ready(mf), t)
+            ideal_next = float(MFMA_PIPE * next_spine)
+            # slip of the real timeline against the ideal one: deadlines move with it
+            slip = max(0.0, start - ideal_next)
+            best = None
             for i in fillers:
-                if t + items[i].cost <= start + 0.5 or t + items[i].cost <= pipe_free + 0.5:
-                    if data_ready(i) <= t + 0.5:
-                        place(i)
-                        placed_filler = True
-                        break
-            if placed_filler:
+                dr = max(data_ready(i), t)
+                key = (alap[i], i)
+                fits = dr + items[i].cost <= start + 0.5
+                urgent = alap[i] + slip < start + MFMA_ISSUE      # waiting for the MFMA would make it late
+                if (fits or urgent) and (best is None or key < best[0]):
+                    best = (key, i, dr)
+            if best is not None:
+                place(best[1], best[2])
                 continue
-            # nothing fits: would a not-yet-ready filler be the better use of the wait?  take the earliest-ready one
-            # if it becomes ready before the MFMA could start anyway
-            cand = [(data_ready(i), i) for i in fillers]
-            cand = [c for c in cand if c[0] + items[c[1]].cost <= start + 0.5]
-            if cand:
-                tr, i = min(cand)
-                t = max(t, tr)
-                place(i)
-                continue
-            t = max(t, start - 0.0)
-            place(mf)
+            place(mf, start)
             continue
         if not fillers:
             raise RuntimeError("scheduler stuck: dependence cycle?")
-        # no MFMA placeable: take fillers in program order (the one whose data is ready first, ties by order)
-        cand = sorted((max(data_ready(i), t), i) for i in fillers)
-        tr, i = cand[0]
-        t = max(t, tr) if items[i].kind not in ("wait", "barrier") else t
-        place(i)
+        # the next MFMA waits for fillers: most urgent first
+        cand = sorted((alap[i], i) for i in fillers)
+        i = cand[0][1]
+        at = max(data_ready(i), t) if items[i].kind not in ("wait", "barrier") else t
+        place(i, at)
     if verbose:
-        nm = sum(1 for i in out if items[i].kind == "mfma")
-        print("schedule: %d instructions, %d MFMA, modelled %.0f cycles (MFMA floor %d)" % (n, nm, max(t, pipe_free), nm * MFMA_PIPE))
+        print("schedule: %d instructions, %d MFMA, modelled %.0f cycles (MFMA floor %d)"
+              % (n, len(spine), max(t, pipe_free), t_end))
     return [items[i] for i in out]
 
 
