@@ -91,6 +91,12 @@ const char* sfa_last_path(void);
  *   [2] after the dK/dV kernel, [3] after the dQ kernel (= end of sfa_bwd).
  * Process-global and not thread-safe by design: a diagnostic, never used by the op itself.
  */
+/* Development hook: in a library built with -DSFA_AB two variants of a kernel body are compiled side by side and
+ * `value` picks the one `which` (0 dK/dV, 1 forward, 2 dQ) launches, so that tools/ab.py can time them alternately in
+ * one process on one device.  No effect in a release build. */
+int sfa_debug_set_variant(int which, int value);
+/* Device buffer for the cycle stamps of a diagnostic build (tools/stamps_dkdv.py); unused otherwise. */
+int sfa_debug_set_ptr(void* device_buffer);
 int sfa_debug_set_stage_events(void* const* events, int count);
 
 /*

@@ -12,6 +12,8 @@ static thread_local char g_err[512] = "";
 static char g_path[128] = "";  // diagnostic only: last kernel family dispatched in this process (any thread)
 
 // measurement hook (sfa_debug_set_stage_events): process-global on purpose, the autograd thread runs sfa_bwd
+void* g_debug_ptr = nullptr;
+int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sfa_debug_set_variant: A/B builds (-DSFA_AB) only
 static void* const* g_stage_events = nullptr;
 static int g_stage_count = 0;
 void record_stage(int i, hipStream_t stream) {
@@ -115,6 +117,17 @@ extern "C" {
 int sfa_abi_version(void) { return SFA_ABI_VERSION; }
 const char* sfa_last_error(void) { return g_err; }
 const char* sfa_last_path(void) { return g_path; }
+int sfa_debug_set_variant(int which, int value) {
+    if (which < 0 || which >= 8) return SFA_ERR_INVALID_ARGUMENT;
+    __atomic_store_n(&sfa::g_variant[which], value, __ATOMIC_RELAXED);
+    return SFA_OK;
+}
+
+int sfa_debug_set_ptr(void* p) {
+    sfa::g_debug_ptr = p;
+    return SFA_OK;
+}
+
 int sfa_debug_set_stage_events(void* const* events, int count) {
     g_stage_events = count > 0 ? events : nullptr;
     g_stage_count = count > 0 ? count : 0;

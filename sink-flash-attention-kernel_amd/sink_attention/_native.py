@@ -48,6 +48,10 @@ def _bind(lib):
     lib.sfa_last_error.argtypes = []
     lib.sfa_last_path.restype = ctypes.c_char_p
     lib.sfa_last_path.argtypes = []
+    lib.sfa_debug_set_ptr.restype = i32
+    lib.sfa_debug_set_ptr.argtypes = [ctypes.c_void_p]
+    lib.sfa_debug_set_variant.restype = i32
+    lib.sfa_debug_set_variant.argtypes = [i32, i32]
     lib.sfa_debug_set_stage_events.restype = i32
     lib.sfa_debug_set_stage_events.argtypes = [ctypes.POINTER(ctypes.c_void_p), i32]
     lib.sfa_fwd.restype = i32

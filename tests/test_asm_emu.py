@@ -67,3 +67,12 @@ def test_scheduled_body_equals_program_order_bitwise():
 def test_body_assembles_for_gfx950(dtype):
     ok, err = assemble(_prog(dtype, True))
     assert ok, err[:4000]
+
+
+def test_stamped_diagnostic_body_runs_and_agrees():
+    """the s_memtime-stamped build of the body (tools/stamps_dkdv.py) stores only into its own debug records and
+    computes the same gradients"""
+    q, k, v, do, lse, delta, _, _ = _case(1, 2, 1, 96, 290, 4, 70, "bf16", seed=5)
+    a = run_dkdv(_prog("bf16", True), q, k, v, do, lse, delta, 4, 70, "bf16")
+    b = run_dkdv(DkdvGen("bf16", stamps=True).build(), q, k, v, do, lse, delta, 4, 70, "bf16", stamped=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

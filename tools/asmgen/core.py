@@ -160,6 +160,8 @@ class Instr:
             return "s_nop %d" % m["n"]
         if self.op == "s_setprio":
             return "s_setprio %d" % m["n"]
+        if self.op == "s_memtime":
+            return "s_memtime %s" % self.dst[0].text()
         if k in ("ds_read", "ds_write"):
             ops = [d.text() for d in self.dst] + [s.text() for s in self.src]
             t = "%s %s" % (self.op, ", ".join(ops))

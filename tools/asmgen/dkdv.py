@@ -64,10 +64,13 @@ class Alloc:
 
 
 class DkdvGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=8, sfirst=56):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.do_sched = sched
+        self.stamps = stamps            # diagnostic build: s_memtime around the loop head, sums stored per workgroup
+        if stamps:
+            npool = min(npool, 11)
         self.va = Alloc("v", vfirst, 255)
         self.sa = Alloc("s", sfirst, 99)      # s100 / s101 are reserved by the compiler
         self.vfirst, self.sfirst = vfirst, sfirst
@@ -75,7 +78,7 @@ class DkdvGen:
         # ---------------- VGPRs
         self.KF = [[va("kf%d_%d" % (kbi, ks), 4, 4) for ks in range(8)] for kbi in range(2)]
         self.QROW = [va("qrow%d" % ks, 4, 4) for ks in range(8)]
-        self.POOL = [va("pool%d" % i, 4, 4) for i in range(8)]
+        self.POOL = [va("pool%d" % i, 4, 4) for i in range(npool)]   # streamed MFMA operand fragments (LDS -> here -> MFMA)
         self.SACC = [va("sacc%d" % kbi, 16, 4) for kbi in range(2)]
         self.DPACC = [va("dpacc%d" % kbi, 16, 4) for kbi in range(2)]
         self.PPK = [[va("ppk%d_%d" % (kbi, s), 4, 4) for s in range(2)] for kbi in range(2)]
@@ -96,8 +99,10 @@ class DkdvGen:
         self.v_kh = va("v_kh")
         self.v_weff = [va("v_weff0"), va("v_weff1")]
         self.v_d = [va("v_d0"), va("v_d1")]
-        self.tmp = [va("tmp%d" % i) for i in range(4)]
-        self.vo_k = [va("vo_k0"), va("vo_k1")]      # prologue (K fragment loads) / epilogue (store offsets) scratch
+        # scratch of the prologue / epilogue lives in registers the loop owns (the last two Q row fragments: loaded at
+        # the very end of the prologue, dead in the epilogue); only tmp[0] is used inside the loop (edge trips)
+        self.tmp = [va("tmp0"), self.QROW[6][0], self.QROW[6][1], self.QROW[6][2]]
+        self.vo_k = [self.QROW[6][3], self.QROW[7][0]]      # K fragment load / dK, dV store offsets
         # ---------------- AGPRs
         self.DV = [[A((db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(4)]
         self.DK = [[A(128 + (db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(4)]
@@ -117,6 +122,16 @@ class DkdvGen:
         self.s_wofs = sa("s_wofs")                # 2048 * wave: the wave's two DMA pieces inside a slice image
         self.s_tmp = [sa("s_tmp%d" % i) for i in range(4)]
         self.pool_next = 0
+        if stamps:
+            self.v_sum = [va("sum_top"), va("sum_body"), va("sum_n")]
+            self.s_ta, self.s_tb = self.d_x[0:2], self.d_x[2:4]      # the prologue / epilogue descriptor is idle in the loop
+
+    def params(self):
+        return PARAMS + (["dbg_lo", "dbg_hi", "bid"] if self.stamps else [])
+
+    def emit_stamp(self, p: Prog, dst):
+        p.add(Instr("s_memtime", [dst], [], kind="misc"))
+        p.s_waitcnt(lgkmcnt=0)
 
     # ------------------------------------------------------------------ helpers
     def pool(self):
@@ -194,12 +209,18 @@ class DkdvGen:
         p.s_or_b32(t1, t1, self.s_allsink)
         p.s_and_b32(self.s_full, t0, t1)
 
-    def emit_next_prefetch(self, p: Prog):
-        """operands of the next trip's S chains: Q row fragments and the -LSE/scale rows as initial accumulators"""
+    def emit_next_prefetch(self, p: Prog, deadline=None):
+        """operands of the next trip's S chains: Q row fragments and the -LSE/scale rows as initial accumulators.
+        `deadline`: latest issue time inside a trip (nothing in the trip needs them, but the next trip starts with
+        them: they have to be on their way well before the trip ends)"""
+        n0 = len(p.items)
         self.emit_qrow_prefetch(p, self.a_rown_e, self.a_rown_o)
         for kbi in range(2):
             for g4 in range(4):
                 p.ds_read_b128(self.SACC[kbi][4 * g4:4 * g4 + 4], self.a_cn, 32 * g4, mem=("stage_r",))
+        if deadline is not None:
+            for k, it in enumerate(p.items[n0:]):
+                it.mods["alap"] = deadline + 6 * k
 
     def emit_qrow_prefetch(self, p: Prog, e, o):
         for ks in range(8):
@@ -388,6 +409,11 @@ class DkdvGen:
         p.s_mov(self.s_cst, CST_BASE)
         p.s_mov(self.s_cstn, CST_BASE + 256)
         p.s_mov(self.s_cstd, CST_BASE + 768)
+        if self.stamps:
+            for r in self.v_sum:
+                p.v_mov(r, 0)
+            p.s_waitcnt(lgkmcnt=0)
+            self.emit_stamp(p, self.s_tb)
         return p
 
     # ------------------------------------------------------------------ loop head (scalar, branchy)
@@ -395,6 +421,10 @@ class DkdvGen:
         """common path: 8 scalar instructions + the trip's wait / barrier; the two head changes are out of line"""
         p = Prog()
         p.label("L_top%=")
+        if self.stamps:      # body time of the trip that just ended: now - (stamp behind its barrier)
+            self.emit_stamp(p, self.s_ta)
+            p.s_sub_u32(self.s_tmp[3], self.s_ta[0], self.s_tb[0])
+            p.v_add_u32(self.v_sum[1], self.s_tmp[3], self.v_sum[1])
         p.s_cmp("ge_u32", self.s_t, self.s_n)
         p.s_cbranch("scc1", "L_done%=")
         p.s_cmp("lt_u32", self.s_ldq, P("nq"))
@@ -407,6 +437,13 @@ class DkdvGen:
         p.s_waitcnt(vmcnt=5, note="slice t+1 landed (own pieces); slice t+2 may be in flight")
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="S-chain operands of this slice (fetched at the end of the last trip)")
+        if self.stamps:      # head time: loop head + waits + barrier
+            p.s_mov(self.s_tmp[3], self.s_full)
+            self.emit_stamp(p, self.s_tb)
+            p.s_sub_u32(self.s_tmp[2], self.s_tb[0], self.s_ta[0])
+            p.v_add_u32(self.v_sum[0], self.s_tmp[2], self.v_sum[0])
+            p.v_add_u32(self.v_sum[2], 1, self.v_sum[2])
+            p.s_cmp("lg_u32", self.s_tmp[3], 0)
         p.s_cbranch("scc0", "L_edge%=")
         return p
 
@@ -497,7 +534,7 @@ class DkdvGen:
                         else:
                             p.mfma(dt, self.DK[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DK[db][kbi], tag="dK")
         # operands of the next trip (stage t + 1, landed before this trip's barrier)
-        self.emit_next_prefetch(p)
+        self.emit_next_prefetch(p, deadline=64 * 32 - 420)
         # scalar state of the next trip (its class assumes the same q head; a head change redoes it out of line)
         p.s_add_u32(self.s_q0p, self.s_q0p, 32)
         p.s_add_u32(self.s_t, self.s_t, 1)
@@ -525,6 +562,21 @@ class DkdvGen:
         t0, t1, t2, t3 = self.tmp
         p.label("L_done%=")
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        if self.stamps:
+            # lane 0..2 of every wave: sum_top, sum_body, trips at dbg[(4 bid + wave) * 4 + lane] (other lanes out of range)
+            p.s_mov(self.d_x[0], P("dbg_lo"))
+            p.s_mov(self.d_x[1], P("dbg_hi"))
+            p.s_mov(self.d_x[3], 0x00020000)
+            p.s_lshl_b32(self.s_tmp[0], P("bid"), 2)
+            p.s_add_u32(self.s_tmp[0], self.s_tmp[0], self.s_wave)
+            p.s_lshl_b32(self.s_tmp[0], self.s_tmp[0], 4)
+            p.s_add_u32(self.d_x[2], self.s_tmp[0], 16, note="records end behind this wave's 16 bytes")
+            for k, r in enumerate(self.v_sum):
+                p.v_mov(t0, self.s_tmp[0])
+                p.v_cmp("eq_u32", 0, self.lane)
+                p.v_cndmask(t0, self.v_oob, t0)
+                p.buffer_store(r, t0, self.d_x, 0, offset=4 * k)
+            p.s_waitcnt(vmcnt=0)
         # store offsets: key (block kbi) * row stride + 8 h bytes ; d = 32 db + 8 g4 + 4 h -> immediate 64 db + 16 g4
         p.s_lshl_b32(self.s_tmp[0], self.s_wave, 6)
         p.s_add_u32(self.s_tmp[0], self.s_tmp[0], P("kb0"))
@@ -543,7 +595,7 @@ class DkdvGen:
             for kbi in range(2):
                 for db in range(4):
                     for g4 in range(4):
-                        regs = self.POOL[(db * 4 + g4) % 8]
+                        regs = self.POOL[(db * 4 + g4) % 8]                 # 8 staging sets: a set is rewritten 7 stores later
                         for e in range(4):
                             p.v_accvgpr_read(regs[e], acc[db][kbi][4 * g4 + e])
                         if which == "dk":

@@ -309,7 +309,10 @@ class Workgroup:
     # ---- kinds
     def x_nop(self, w, ins): pass
 
-    def x_misc(self, w, ins): pass
+    def x_misc(self, w, ins):
+        if ins.op == "s_memtime":
+            w.s[ins.dst[0].idx] = w.icount & 0xFFFFFFFF       # a clock that ticks once per instruction
+            w.s[ins.dst[0].idx + 1] = 0
 
     def x_wait(self, w, ins):
         m = ins.mods
@@ -504,6 +507,8 @@ class Workgroup:
         for j in range(d.n):
             bank[d.idx + j] = words[:, j].astype(U32)
         w.lgkm.append(("regs", set(d.regs())))
+        if len(w.lgkm) > 15:          # 4-bit counter: the 16th operation issues only once the oldest has completed
+            del w.lgkm[:len(w.lgkm) - 15]
 
     def x_ds_write(self, w, ins):
         nbytes = {"ds_write_b128": 16, "ds_write_b64": 8, "ds_write_b32": 4}[ins.op]

@@ -39,7 +39,8 @@ def dkdv_block_params(N, Nk, D, Hq, Hkv, ns, window, kb):
     return dict(P=P, W=W, kb0=kb0, qt_lo=qt_lo, nq=qt_hi - qt_lo)
 
 
-def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, blocks=None, stats=None):
+def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, blocks=None, stats=None,
+             stamped=False):
     """q, do [B, Hq, N, D]; k, v [B, Hkv, Nk, D] (torch, bf16 / f16); lse, delta [B, Hq, N] float.
     Returns dk, dv [B, Hkv, Nk, D] float32 (as stored by the kernel: 16-bit values)."""
     B, Hq, N, D = q.shape
@@ -54,6 +55,7 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
     adk = mem.alloc_zero(B * Hkv * Nk * D * 2)
     adv = mem.alloc_zero(B * Hkv * Nk * D * 2)
     nkb = (Nk + 255) // 256
+    dbg = mem.alloc_zero(B * Hkv * nkb * 64) if stamped else None
     for b in range(B):
         for hk in range(Hkv):
             for kb in range(nkb):
@@ -81,6 +83,8 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
                     nq=bp["nq"], g=g, q_row0=bp["qt_lo"] * 32, kb0=bp["kb0"], pos0=bp["P"], W=bp["W"], ns=ns, nrows=N,
                     cdelta=N * 4, c_log2=f32_bits(scale * math.log2(math.e)), scale=f32_bits(scale))
                 assert set(params) == set(K.PARAMS), set(params) ^ set(K.PARAMS)
+                if dbg is not None:      # stamped diagnostic body
+                    params.update(dbg_lo=dbg & 0xFFFFFFFF, dbg_hi=dbg >> 32, bid=(b * Hkv + hk) * nkb + kb)
                 wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
                 wg.run()
                 if stats is not None:

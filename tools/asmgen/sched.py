@@ -15,9 +15,11 @@ from .core import Imm, Instr, Prog, Reg
 
 MFMA_PIPE = 32      # cycles of the matrix pipe per v_mfma_f32_32x32x16
 MFMA_ISSUE = 8      # cycles the MFMA holds the wave's issue
-LDS_LAT = 128       # issue -> data, modelled (a wait is inserted wherever the consumer really sits)
+LDS_LAT = 200       # issue -> data under load, modelled (a wait is inserted wherever the consumer really sits)
 MFMA_LAT = 64       # issue -> result readable by a non-MFMA instruction, modelled
 VALU_LAT = 8
+SATURATION_WAITS = False
+MAX_LDS_INFLIGHT = 12   # LDS reads a wave keeps in flight (the hardware counter saturates at 15)
 
 
 def _is_fence(it: Instr) -> bool:
@@ -130,6 +132,12 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
     t = 0.0
     pipe_free = 0.0
     next_spine = 0
+    lds_inflight: List[float] = []      # modelled completion times of the LDS reads in flight (lgkmcnt counts to 15)
+
+    def lds_room(at: float) -> bool:
+        while lds_inflight and lds_inflight[0] <= at:
+            lds_inflight.pop(0)
+        return len(lds_inflight) < MAX_LDS_INFLIGHT
 
     def data_ready(i: int) -> float:
         tt = 0.0
@@ -147,6 +155,8 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
             next_spine += 1
         else:
             t = at + it.cost
+            if it.kind == "ds_read":
+                lds_inflight.append(at + LDS_LAT)
         out.append(i)
         ready.discard(i)
         for u in users[i]:
@@ -167,6 +177,8 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
             best = None
             for i in fillers:
                 dr = max(data_ready(i), t)
+                if items[i].kind == "ds_read" and not lds_room(dr):
+                    continue                      # the LDS queue is full: reads wait for a later gap
                 key = (alap[i], i)
                 fits = dr + items[i].cost <= start + 0.5
                 urgent = alap[i] + slip < start + MFMA_ISSUE      # waiting for the MFMA would make it late
@@ -183,6 +195,9 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
         cand = sorted((alap[i], i) for i in fillers)
         i = cand[0][1]
         at = max(data_ready(i), t) if items[i].kind not in ("wait", "barrier") else t
+        if items[i].kind == "ds_read" and not lds_room(at):
+            at = max(at, lds_inflight[0])
+            lds_room(at)
         place(i, at)
     if verbose:
         print("schedule: %d instructions, %d MFMA, modelled %.0f cycles (MFMA floor %d)"
@@ -242,13 +257,17 @@ def insert_waits(items: Sequence[Instr], strict: bool = False, strict_tail: bool
             vm.append(set(it.writes()))
         elif k in ("dma", "vstore"):
             vm.append(set())
+        # lgkmcnt is a 4-bit counter: the hardware holds the 16th LDS operation back until the oldest one has
+        # completed, so at most 15 are ever outstanding and the oldest entries beyond that are known to be done
         if len(lgkm) > 15:
-            # the counter saturates at 15: keep the model exact by waiting explicitly (rare: >15 reads in flight)
-            w = Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 15})
-            out.append(it)
-            out.append(w)
+            if SATURATION_WAITS:     # A/B knob: the explicit form (an s_waitcnt lgkmcnt(15) behind every such read)
+                out.append(it)
+                out.append(Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 15}))
+                del lgkm[:len(lgkm) - 15]
+                continue
             del lgkm[:len(lgkm) - 15]
-            continue
+        if len(vm) > 63:
+            del vm[:len(vm) - 63]
         out.append(it)
     return out
 
