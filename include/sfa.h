@@ -55,11 +55,8 @@ extern "C" {
 
 /* flags */
 #define SFA_FLAG_FORCE_GENERIC 0x1u /* use the exact-f32 generic kernels even when an MFMA kernel exists */
-/* sfa_bwd / sfa_bwd_workspace_bytes: trade workspace for recompute.  The dK/dV kernel saves dS (16 bit, 2 bytes
- * per valid (query, key) pair per q head) in the workspace and dQ becomes a plain GEMM over it instead of a second
- * recompute of S and dP.  The workspace query reports the larger size; pass the SAME flags to both calls.  Ignored
- * (no extra workspace) where the MFMA backward does not apply. */
-#define SFA_FLAG_BWD_SPILL_DS 0x2u
+/* 0x2u was SFA_FLAG_BWD_SPILL_DS in ABI revisions before round 2 (dS saved by the dK/dV kernel, dQ as a GEMM over it:
+ * break-even against 7 GB of workspace, removed).  The bit is accepted and ignored. */
 /* sfa_decode*: one launch instead of two.  The last KV split of a (batch, KV head) to finish folds the split partials
  * itself (atomic arrival counters).  Contract: the caller OWNS the workspace across calls and zero-initialised its FIRST
  * align256((B * Hkv + 1) * 4) bytes once; the kernel leaves them zero.  Worth it at small batch, where a decode step is

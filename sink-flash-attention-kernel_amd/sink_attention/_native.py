@@ -18,9 +18,7 @@ LIB_PATH = os.environ.get("SFA_LIB_PATH") or os.path.join(_HERE, "libsfa.so")   
 
 SFA_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 FLAG_FORCE_GENERIC = 0x1
-FLAG_BWD_SPILL_DS = 0x2
 FLAG_DECODE_ONE_PASS = 0x4
-DS_SPILL_DEFAULT_GB = "0"     # default cap of the dS-spill backward workspace (see sink_flash_attention._ds_spill_cap_bytes)
 ABI_VERSION = 1
 
 

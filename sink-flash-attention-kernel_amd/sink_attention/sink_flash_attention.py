@@ -25,12 +25,6 @@ import torch
 from . import _native as N
 
 
-def _ds_spill_cap_bytes() -> int:
-    """Largest extra backward workspace (bytes) the op may take to save dS for the dQ GEMM (SFA_FLAG_BWD_SPILL_DS)
-    instead of recomputing S and dP in the dQ kernel.  Env SINK_ATTENTION_DS_SPILL_GB (float, 0 disables)."""
-    return int(float(os.environ.get("SINK_ATTENTION_DS_SPILL_GB", N.DS_SPILL_DEFAULT_GB)) * (1 << 30))
-
-
 class SinkFlashAttentionFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, num_sink, window_size, s_aux=None, out_bnhd=False, flags=0):
@@ -90,13 +84,8 @@ class SinkFlashAttentionFunc(torch.autograd.Function):
         ds_aux = mk((H_q,), device=q.device, dtype=torch.float32) if ctx.use_s_aux else None
         lib = N.lib()
         flags = ctx.flags
-        ws_args = (B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink, ctx.window_size)
-        ws_bytes = lib.sfa_bwd_workspace_bytes(*ws_args, flags)
-        cap = _ds_spill_cap_bytes()
-        if cap > 0 and not (flags & N.FLAG_FORCE_GENERIC) and k.shape[2] == Nq:
-            spill_bytes = lib.sfa_bwd_workspace_bytes(*ws_args, flags | N.FLAG_BWD_SPILL_DS)
-            if ws_bytes < spill_bytes <= ws_bytes + cap:
-                flags, ws_bytes = flags | N.FLAG_BWD_SPILL_DS, spill_bytes
+        ws_bytes = lib.sfa_bwd_workspace_bytes(B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink,
+                                               ctx.window_size, flags)
         ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)
         with torch.cuda.device(q.device):
             st = lib.sfa_bwd(N.desc(q), N.desc(k), N.desc(v), N.desc(o), N.desc(do), lse.data_ptr(),

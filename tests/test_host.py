@@ -174,17 +174,14 @@ def test_varlen_bounds_and_default_fallback():
     assert vp.ENABLE_VARLEN is False          # default = the reference's fallback behaviour for packed batches
 
 
-def test_spill_workspace_query_and_varlen_support_need_no_gpu():
+def test_workspace_query_ignores_retired_flag_and_varlen_support_needs_no_gpu():
     from sink_attention import _native
     lib = _native.lib()
     args = (4, 32, 8, 8192, 128, 2, 4, 4096)
     base = lib.sfa_bwd_workspace_bytes(*args, 0)
-    spill = lib.sfa_bwd_workspace_bytes(*args, _native.FLAG_BWD_SPILL_DS)
-    # 2 bytes per (query, key) pair of the sink + window band and q head, in 32 x 128 chunks: 6460 chunks per head
-    assert spill - base >= 4 * 32 * 6460 * 8192 and spill - base < 4 * 32 * 6460 * 8192 + (1 << 20)
-    # fp32 / generic path: the flag is ignored
-    assert lib.sfa_bwd_workspace_bytes(4, 32, 8, 8192, 128, 0, 4, 4096, _native.FLAG_BWD_SPILL_DS) == \
-        lib.sfa_bwd_workspace_bytes(4, 32, 8, 8192, 128, 0, 4, 4096, 0)
+    # Delta + ds_aux partials + the row constants [B, Hq, 2, N] f32 of the dK/dV kernels; flag bit 0x2 (the retired dS
+    # spill) changes nothing
+    assert base >= 3 * 4 * 32 * 8192 * 4 and lib.sfa_bwd_workspace_bytes(*args, 0x2) == base
     assert lib.sfa_varlen_supported(2, 128) == 1 and lib.sfa_varlen_supported(1, 64) == 1
     assert lib.sfa_varlen_supported(0, 128) == 0 and lib.sfa_varlen_supported(2, 256) == 0
 
