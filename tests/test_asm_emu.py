@@ -14,16 +14,17 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 from asmgen.asmcheck import CLANG, assemble          # noqa: E402
 from asmgen.dkdv import DkdvGen                       # noqa: E402
-from asmgen.harness import run_dkdv                   # noqa: E402
+from asmgen.dq import DqGen                           # noqa: E402
+from asmgen.harness import run_dkdv, run_dq           # noqa: E402
 from oracle import sink_oracle as O                   # noqa: E402
 
 _PROGS = {}
 
 
-def _prog(dtype, sched):
-    key = (dtype, sched)
+def _prog(dtype, sched, gen=DkdvGen):
+    key = (dtype, sched, gen)
     if key not in _PROGS:
-        _PROGS[key] = DkdvGen(dtype, sched=sched).build()
+        _PROGS[key] = gen(dtype, sched=sched).build()
     return _PROGS[key]
 
 
@@ -35,7 +36,8 @@ def _case(B, Hq, Hkv, N, Nk, ns, W, dtype, seed):
     k, v = (torch.randn(B, Hkv, Nk, D, generator=g).to(td) for _ in range(2))
     o, lse = O.sink_attention_dense(q, k, v, ns, W)
     delta = (do.double() * o).sum(-1)
-    _, dk, dv, _ = O.sink_attention_bwd_dense(q, k, v, do, ns, W)
+    dq, dk, dv, _ = O.sink_attention_bwd_dense(q, k, v, do, ns, W)
+    _case.dq = dq
     return q, k, v, do, lse, delta, dk, dv
 
 
@@ -76,3 +78,31 @@ def test_stamped_diagnostic_body_runs_and_agrees():
     a = run_dkdv(_prog("bf16", True), q, k, v, do, lse, delta, 4, 70, "bf16")
     b = run_dkdv(DkdvGen("bf16", stamps=True).build(), q, k, v, do, lse, delta, 4, 70, "bf16", stamped=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,Nk,ns,W,dtype", [
+    (1, 4, 1, 300, 300, 4, 100, "bf16"),      # 4 heads x 64 rows per workgroup, sink tile + window tiles, ragged rows
+    (1, 2, 2, 333, 333, 70, 50, "f16"),       # MHA: one head x 256 rows per workgroup; sinks over two key tiles
+    (2, 2, 1, 77, 200, 3, 64, "bf16"),        # 2 heads x 128 rows; N_q < N_kv
+    (1, 2, 1, 40, 40, 4, 1, "bf16"),          # window of one key
+])
+def test_dq_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype):
+    q, k, v, do, lse, delta, _, _ = _case(B, Hq, Hkv, N, Nk, ns, W, dtype, seed=N + 1)
+    ref = _case.dq
+    got = run_dq(_prog(dtype, True, DqGen), q, k, v, do, lse, delta, ns, W, dtype)
+    err = (got.double() - ref).abs()
+    assert (err <= 5e-2 + 5e-2 * ref.abs()).all() and err.max().item() < 3e-2, err.max().item()
+
+
+def test_dq_scheduled_body_equals_program_order_bitwise():
+    q, k, v, do, lse, delta, _, _ = _case(1, 4, 1, 200, 200, 4, 70, "bf16", seed=6)
+    a = run_dq(_prog("bf16", False, DqGen), q, k, v, do, lse, delta, 4, 70, "bf16")
+    b = run_dq(_prog("bf16", True, DqGen), q, k, v, do, lse, delta, 4, 70, "bf16")
+    assert torch.equal(a, b)
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm assembler not installed")
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_dq_body_assembles_for_gfx950(dtype):
+    ok, err = assemble(_prog(dtype, True, DqGen))
+    assert ok, err[:4000]

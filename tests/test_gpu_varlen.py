@@ -67,7 +67,7 @@ def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu):
     out = sink_flash_attention_varlen(qd, kd, vd, cu, num_sink=ns, window_size=W, s_aux=sad)
     assert _native.last_path().startswith("fwd_mfma")
     out.backward(do.to(DEV))
-    assert "dkdvws8" in _native.last_path()
+    assert "dkdvws8" in _native.last_path() or "dkdvasm4x64" in _native.last_path()
     o_r, dq_r, dk_r, dv_r, dsa_r = _per_seq_oracle(q, k, v, do, cu, ns, W, sa)
     assert maxdiff(out, o_r) < 2e-2
     assert maxdiff(qd.grad, dq_r) < 1.5e-1 and maxdiff(kd.grad, dk_r) < 1.5e-1 and maxdiff(vd.grad, dv_r) < 1.5e-1

@@ -1,0 +1,447 @@
+"""Generator of the hand-placed dQ backward kernel body (gfx950, head dim 128, bf16 / f16).
+
+Replaces _sink_flash_attn_bwd_dq_kernel of the reference (sink_attention/sink_flash_attention.py:371-484); same maths
+as csrc/sfa_bwd_mfma.hip's bwd_dq_mfma_kernel (Q-stationary, S and dP recomputed), different machine mapping:
+
+  workgroup = 4 waves; wave w = 64 query rows (two 32-row blocks rb) of ONE q head: HPW = gcd(group, 4) heads of the
+  GQA group x 4 / HPW row groups share every 64-key K / V tile through LDS.  One wave per SIMD, 512 registers:
+      Q and dO fragments of the wave's rows (B operands) live in 128 accumulator registers for the whole workgroup,
+      dQ^T [d, row] accumulates in the other 128.
+  Per tile (64 keys = two 32-key halves kh) and wave, 96 MFMAs:
+      S^T[key,row]  = K Q^T          4 chains x 8   (A: K row fragments from LDS, 8 fragments feed both row blocks)
+      dP^T[key,row] = V dO^T         4 chains x 8   (A: V row fragments from LDS)
+      P = exp2(c S - LSE log2e), dS = P (dP - Delta)   VALU on 16 elements per lane and chain, packed in place
+      dQ^T[d,row]  += K^T dS^T       32             (A: transposed LDS reads of the SAME K image, B: packed dS)
+  Spine order S00 S01 dP00 dP01 S10 S11 dP10 dP11 dQ(kh0) dQ(kh1): the VALU work of a chain pair runs in the gaps of the
+  next 16 MFMAs.  K / V tiles arrive by LDS-DMA three tiles ahead into a 4-deep ring (8 pieces per wave and tile); one
+  s_barrier per tile.
+
+LDS map: 4 stages x (K image 16 KB | V image 16 KB) from byte 0; images are the dual-use 8-row x 32-column subtile
+layout of dkdv.py.
+"""
+from __future__ import annotations
+
+from .core import A, Imm, Instr, M0, P, PV, Prog, Reg, S, V, VCC, imm
+from .dkdv import Alloc
+from .sched import finish_block, fix_hazards, insert_waits, schedule
+
+STG_BYTES = 32768
+NSTAGE = 4
+LDS_BYTES = NSTAGE * STG_BYTES
+
+PARAMS = [
+    "q_lo", "q_hi", "q_hs", "q_sn", "q_rng",
+    "do_lo", "do_hi", "do_hs", "do_sn", "do_rng",
+    "dq_lo", "dq_hi", "dq_hs", "dq_sn", "dq_rng",
+    "k_lo", "k_hi", "k_sn", "k_rng", "v_lo", "v_hi", "v_sn", "v_rng",
+    "lse_lo", "lse_hi", "dl_lo", "dl_hi", "ld_hs",          # LSE / Delta [.., head, row] f32; head stride in bytes
+    "q0", "nrows", "pos0", "W", "ns", "nt", "ts_hi", "tw_off",     # tile it -> it < ts_hi ? it : it + tw_off
+    "hpw_log2", "c_log2", "nlog2e", "scale",
+]
+# q_*/do_*/dq_*/lse/dl bases point at (first head of the workgroup's head set, the sequence's first row); q0 = first row
+# of the workgroup; nlog2e = -log2(e) (f32 bits).
+
+
+class DqGen:
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12):
+        assert dtype in ("bf16", "f16")
+        self.dtype, self.do_sched = dtype, sched
+        self.vfirst, self.sfirst = vfirst, sfirst
+        va = self.va = Alloc("v", vfirst, 255)
+        sa = self.sa = Alloc("s", sfirst, 99)
+        # ---------------- VGPRs
+        self.SACC = [[va("sacc%d%d" % (kh, rb), 16, 4) for rb in range(2)] for kh in range(2)]
+        self.DPACC = [[va("dpacc%d%d" % (kh, rb), 16, 4) for rb in range(2)] for kh in range(2)]
+        self.POOL = [va("pool%d" % i, 4, 4) for i in range(npool)]
+        self.lse2 = [va("lse2_%d" % rb) for rb in range(2)]       # -LSE * log2(e) of the lane's row
+        self.nd = [va("nd_%d" % rb) for rb in range(2)]           # Delta of the lane's row
+        self.lane, self.lane31 = va("lane"), va("lane31")
+        self.l_row_e, self.l_tr0 = va("l_row_e"), va("l_tr0")
+        self.a_k_e, self.a_k_o, self.a_v_e, self.a_v_o = va("a_k_e"), va("a_k_o"), va("a_v_e"), va("a_v_o")
+        self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
+        self.a_kn_e, self.a_kn_o = va("a_kn_e"), va("a_kn_o")
+        self.l_dma = [[va("l_dma%d%s" % (e, t)) for t in "kv"] for e in range(2)]
+        self.vt = [va("vt%d" % i) for i in range(2)]               # DMA source offsets of the piece being issued
+        self.v_pos = [va("v_pos%d" % rb) for rb in range(2)]       # key position of the lane's row
+        self.v_d = [va("v_d%d" % rb) for rb in range(2)]
+        self.v_w, self.v_2e31, self.v_nsh, self.v_weff = va("v_w"), va("v_2e31"), va("v_nsh"), va("v_weff")
+        self.tmp = [va("tmp%d" % i) for i in range(4)]
+        self.vo = [va("vo%d" % rb) for rb in range(2)]             # row offsets (prologue loads, epilogue stores)
+        # ---------------- AGPRs
+        self.QF = [[A((rb * 8 + ks) * 4, 4) for ks in range(8)] for rb in range(2)]
+        self.DOF = [[A(64 + (rb * 8 + ks) * 4, 4) for ks in range(8)] for rb in range(2)]
+        self.DQ = [[A(128 + (rb * 4 + db) * 16, 16) for db in range(4)] for rb in range(2)]
+        # ---------------- SGPRs
+        self.d_k, self.d_v, self.d_x = sa("d_k", 4, 4), sa("d_v", 4, 4), sa("d_x", 4, 4)
+        self.s_wave, self.s_hh, self.s_rgi = sa("s_wave"), sa("s_hh"), sa("s_rgi")
+        self.s_pw0, self.s_pwhi = sa("s_pw0"), sa("s_pwhi")
+        self.s_it, self.s_k0 = sa("s_it"), sa("s_k0")
+        self.s_st, self.s_stn, self.s_std = sa("s_st"), sa("s_stn"), sa("s_std")
+        self.s_koff, self.s_voff = sa("s_koff"), sa("s_voff")
+        self.s_wofs = sa("s_wofs")
+        self.s_cls = sa("s_cls")
+        self.s_tmp = [sa("s_tmp%d" % i) for i in range(5)]
+        self.pool_next = 0
+
+    def params(self):
+        return list(PARAMS)
+
+    def pool(self):
+        r = self.POOL[self.pool_next % len(self.POOL)]
+        self.pool_next += 1
+        return r
+
+    # ------------------------------------------------------------------ pieces
+    def emit_tile_of(self, p: Prog, dst, it):
+        """dst = key-tile index of iteration `it` (sink tiles first, then the window tiles)"""
+        p.s_add_u32(dst, it, P("tw_off"))
+        p.s_cmp("lt_u32", it, P("ts_hi"))
+        p.s_cselect(dst, it, dst)
+
+    def emit_dma_tile(self, p: Prog, it_reg, spread=False):
+        """LDS-DMA of the K and V images of iteration it_reg's tile into stage s_std: this wave's 4 + 4 pieces (row
+        groups 2 wave, 2 wave + 1; two 128-byte halves each).  Iterations past the last tile fetch through zero-record
+        descriptors (nothing is read)."""
+        t = self.s_tmp
+        self.emit_tile_of(p, t[0], it_reg)
+        p.s_lshl_b32(t[0], t[0], 6)                        # first key of the tile
+        p.s_mul_i32(self.s_koff, t[0], P("k_sn"))
+        p.s_mul_i32(self.s_voff, t[0], P("v_sn"))
+        p.s_cmp("lt_u32", it_reg, P("nt"))
+        p.s_cselect(self.d_k[2], P("k_rng"), 0)
+        p.s_cselect(self.d_v[2], P("v_rng"), 0)
+        k = 0
+        for img, desc, off, col in ((0, self.d_k, self.s_koff, 0), (16384, self.d_v, self.s_voff, 1)):
+            for e in range(2):
+                for half in range(2):
+                    vt = self.vt[k & 1]
+                    p.v_add_u32(vt, off, self.l_dma[e][col])
+                    if half:
+                        p.v_add_u32(vt, 128, vt)
+                    if k == 0:
+                        p.s_add_u32(t[1], self.s_std, self.s_wofs)
+                        p.s_mov_m0(t[1])
+                    else:
+                        p.s_add_m0(t[1], img + 2048 * e + 1024 * half)
+                    ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage",))
+                    if spread:
+                        ins.mods["alap"] = 40 + 120 * k
+                    k += 1
+
+    def emit_k_prefetch(self, p: Prog, e, o, deadline=None):
+        """first four K row fragments (key half 0, k-steps 0..3) of the next tile, into pool slots 0..3"""
+        for ks in range(4):
+            base = o if ks & 1 else e
+            ins = p.ds_read_b128(self.POOL[ks], base, 512 * (ks >> 1), mem=("stage_r",))
+            if deadline is not None:
+                ins.mods["alap"] = deadline + 6 * ks
+
+    def emit_class(self, p: Prog):
+        """s_cls: 0 full, 1 edge (no sink key in the tile), 2 edge with sink keys.  full <=> k0 + 63 <= pw0 and
+        (k0 + 63 < ns or k0 >= pw_hi - W + 1)"""
+        t = self.s_tmp
+        p.s_add_u32(t[0], self.s_k0, 63)
+        p.s_cmp("le_i32", t[0], self.s_pw0)
+        p.s_cselect(t[1], 1, 0)
+        p.s_cmp("lt_i32", t[0], P("ns"))
+        p.s_cselect(t[2], 1, 0)
+        p.s_sub_i32(t[0], self.s_pwhi, P("W"))
+        p.s_add_i32(t[0], t[0], 1)
+        p.s_cmp("ge_i32", self.s_k0, t[0])
+        p.s_cselect(t[0], 1, 0)
+        p.s_or_b32(t[0], t[0], t[2])
+        p.s_and_b32(t[0], t[0], t[1])                      # full
+        p.s_cmp("lt_i32", self.s_k0, P("ns"))
+        p.s_cselect(t[1], 2, 1)
+        p.s_cmp("lg_u32", t[0], 0)
+        p.s_cselect(self.s_cls, 0, t[1])
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self) -> Prog:
+        p = Prog()
+        t0, t1, t2, t3 = self.tmp
+        st = self.s_tmp
+        lane, wv = self.lane, self.s_wave
+        p.v_and(lane, 63, PV("tid"))
+        p.v_lshrrev(t0, 6, PV("tid"))
+        p.v_readfirstlane(wv, t0)
+        p.v_and(self.lane31, 31, lane)
+        # wave -> head hh = wave & (HPW - 1), row group rgi = wave >> log2(HPW)
+        p.s_lshl_b32(st[0], 1, P("hpw_log2"))
+        p.s_sub_u32(st[0], st[0], 1)
+        p.s_and_b32(self.s_hh, wv, st[0])
+        p.s_lshr_b32(self.s_rgi, wv, P("hpw_log2"))
+        # lane parts of the LDS addresses (see dkdv.py)
+        p.v_lshrrev(t0, 3, self.lane31)
+        p.v_lshlrev(t0, 11, t0)
+        p.v_and(t1, 7, lane)
+        p.v_lshl_add_u32(t0, t1, 6, t0)
+        p.v_bfe_u32(t1, lane, 2, 2)
+        p.v_lshrrev(t2, 5, lane)                              # h
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(self.l_row_e, t1, 4, t0)
+        p.v_bfe_u32(t0, lane, 2, 2)
+        p.v_lshl_add_u32(t0, t2, 2, t0)
+        p.v_lshlrev(t0, 6, t0)
+        p.v_bfe_u32(t1, lane, 4, 1)
+        p.v_bfe_u32(t3, lane, 1, 1)
+        p.v_lshl_add_u32(t1, t1, 1, t3)
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(t0, t1, 4, t0)
+        p.v_and(t1, 1, lane)
+        p.v_lshl_add_u32(self.l_tr0, t1, 3, t0)
+        # row of the lane in block rb: qw0 + 32 rb + r ; qw0 = q0 + 64 rgi
+        p.s_lshl_b32(st[0], self.s_rgi, 6)
+        p.s_add_u32(st[0], st[0], P("q0"))                    # qw0
+        p.s_add_u32(self.s_pw0, st[0], P("pos0"))
+        p.s_add_u32(st[1], st[0], 63)
+        p.s_sub_u32(st[2], P("nrows"), 1)
+        p.s_min_i32(st[1], st[1], st[2])
+        p.s_add_u32(self.s_pwhi, st[1], P("pos0"))
+        p.v_add_u32(t0, st[0], self.lane31)                   # row, rb = 0
+        p.v_add_u32(self.v_pos[0], P("pos0"), t0)
+        p.v_add_u32(self.v_pos[1], 32, self.v_pos[0])
+        # ---- Q and dO fragments of the lane's rows: B operands, chunk 2 ks + h of the row -> accumulator registers
+        for nm, frags in (("q", self.QF), ("do", self.DOF)):
+            p.s_mul_i32(st[1], self.s_hh, P(nm + "_hs"))
+            p.s_mul_hi_u32(st[2], self.s_hh, P(nm + "_hs"))
+            p.s_add_u32(self.d_x[0], P(nm + "_lo"), st[1])
+            p.s_addc_u32(self.d_x[1], P(nm + "_hi"), st[2])
+            p.s_mov(self.d_x[2], P(nm + "_rng"))
+            p.s_mov(self.d_x[3], 0x00020000)
+            p.v_mul_lo_u32(t1, t0, P(nm + "_sn"))
+            p.v_lshl_add_u32(self.vo[0], t2, 4, t1)           # + 16 h
+            p.s_lshl_b32(st[1], P(nm + "_sn"), 5)
+            p.v_add_u32(self.vo[1], st[1], self.vo[0])
+            for rb in range(2):
+                for ks in range(8):
+                    p.buffer_load(frags[rb][ks], self.vo[rb], self.d_x, 0, offset=32 * ks)
+        # ---- row constants: -LSE log2(e) and Delta (rows >= nrows read 0)
+        p.s_mul_i32(st[1], self.s_hh, P("ld_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("ld_hs"))
+        p.v_lshlrev(t1, 2, t0)                                # row * 4
+        p.v_add_u32(t3, 128, t1)
+        for nm, dst in (("lse", self.lse2), ("dl", self.nd)):
+            p.s_add_u32(self.d_x[0], P(nm + "_lo"), st[1])
+            p.s_addc_u32(self.d_x[1], P(nm + "_hi"), st[2])
+            p.s_lshl_b32(self.d_x[2], P("nrows"), 2)
+            p.s_mov(self.d_x[3], 0x00020000)
+            p.buffer_load(dst[0], t1, self.d_x, 0)
+            p.buffer_load(dst[1], t3, self.d_x, 0)
+        for rb in range(2):
+            p.v_mul_f32(self.lse2[rb], P("nlog2e"), self.lse2[rb])
+        # ---- mask constants
+        p.v_mov(self.v_w, P("W"))
+        p.v_mov(self.v_2e31, imm(0x80000000))
+        # ---- K / V streams: descriptors and lane parts of the source offsets.  piece of row group 2 wave + e: rows
+        #      16 wave + 8 e + rr, chunk 4 cbl + (slot ^ ((2 e + (rr >> 2)) & 3))   (+ 8 chunks for the second half)
+        for d, nm in ((self.d_k, "k"), (self.d_v, "v")):
+            p.s_mov(d[0], P(nm + "_lo"))
+            p.s_mov(d[1], P(nm + "_hi"))
+            p.s_mov(d[2], P(nm + "_rng"))
+            p.s_mov(d[3], 0x00020000)
+        rr, slot = t0, t1
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.s_lshl_b32(st[0], wv, 4)
+        for e in range(2):
+            p.v_lshrrev(t3, 2, rr)
+            p.v_add_u32(t3, 2 * e, t3)
+            p.v_and(t3, 3, t3)
+            p.v_xor(t3, t3, slot)
+            p.v_lshl_add_u32(t3, t2, 2, t3)                   # + 4 cbl   (t2 = lane >> 5)
+            p.v_lshlrev(t3, 4, t3)                            # bytes inside the row
+            p.s_add_u32(st[1], st[0], 8 * e)
+            p.v_add_u32(self.vt[0], st[1], rr)                # row inside the tile
+            for col, nm in ((0, "k"), (1, "v")):
+                p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
+                p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+        p.s_lshl_b32(self.s_wofs, wv, 12)                     # 4096 wave: the wave's four pieces inside an image
+        # ---- accumulators
+        for rb in range(2):
+            for db in range(4):
+                for i in range(16):
+                    p.v_accvgpr_write(self.DQ[rb][db][i], 0)
+        # ---- first three tiles into stages 0, 1, 2
+        for j in range(3):
+            p.s_mov(self.s_std, j * STG_BYTES)
+            p.s_mov(st[3], j)
+            self.emit_dma_tile(p, st[3])
+        p.s_waitcnt(vmcnt=16, note="Q / dO fragments, row constants, tile 0 landed (tiles 1, 2 in flight)")
+        p.s_barrier()
+        p.v_mov(self.a_kn_e, self.l_row_e)
+        p.v_xor(self.a_kn_o, 32, self.a_kn_e)
+        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)
+        p.s_mov(self.s_it, 0)
+        p.s_mov(self.s_st, 0)
+        p.s_mov(self.s_stn, STG_BYTES)
+        p.s_mov(self.s_std, 3 * STG_BYTES)
+        return p
+
+    # ------------------------------------------------------------------ loop head
+    def loop_top(self) -> Prog:
+        p = Prog()
+        t = self.s_tmp
+        p.label("L_top%=")
+        p.s_cmp("ge_u32", self.s_it, P("nt"))
+        p.s_cbranch("scc1", "L_done%=")
+        self.emit_tile_of(p, t[0], self.s_it)
+        p.s_lshl_b32(self.s_k0, t[0], 6)
+        self.emit_class(p)
+        p.s_waitcnt(vmcnt=8, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
+        p.s_barrier()
+        p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last trip")
+        p.s_cmp("eq_u32", self.s_cls, 0)
+        p.s_cbranch("scc1", "L_full%=")
+        p.s_cmp("eq_u32", self.s_cls, 1)
+        p.s_cbranch("scc1", "L_edge%=")
+        p.s_branch("L_sink%=")
+        return p
+
+    # ------------------------------------------------------------------ one tile
+    def tile_body(self, cls: int) -> Prog:
+        """cls: 0 full, 1 edge, 2 edge with sink keys"""
+        p = Prog()
+        dt = self.dtype
+        self.pool_next = 0
+        st = self.s_tmp
+        p.v_add_u32(self.a_k_e, self.s_st, self.l_row_e)
+        p.v_xor(self.a_k_o, 32, self.a_k_e)
+        p.v_add_u32(self.a_v_e, 16384, self.a_k_e)
+        p.v_xor(self.a_v_o, 32, self.a_v_e)
+        p.v_add_u32(self.a_tr0, self.s_st, self.l_tr0)
+        p.v_xor(self.a_tr1, 32, self.a_tr0)
+        p.v_add_u32(self.a_kn_e, self.s_stn, self.l_row_e)
+        p.v_xor(self.a_kn_o, 32, self.a_kn_e)
+        # fetch tile it + 3
+        p.s_add_u32(st[4], self.s_it, 3)
+        self.emit_dma_tile(p, st[4], spread=True)
+        if cls:
+            for rb in range(2):      # (pos - k0 - 4 h): u = this - (32 kh + o_v) = pos - key
+                p.v_lshrrev(self.tmp[1], 5, self.lane)
+                p.v_lshlrev(self.tmp[1], 2, self.tmp[1])
+                p.v_add_u32(self.tmp[1], self.s_k0, self.tmp[1])
+                p.v_sub_u32(self.v_d[rb], self.v_pos[rb], self.tmp[1])
+            if cls == 2:             # sink key <=> 32 kh + o_v < ns - k0 - 4 h
+                p.v_sub_u32(self.v_nsh, P("ns"), self.tmp[1])
+        for kh in range(2):
+            # ---- S^T = K Q^T: the eight K row fragments of this key half feed both row blocks
+            kf = []
+            for ks in range(8):
+                f = self.pool()
+                if not (kh == 0 and ks < 4):          # the first four were fetched at the end of the previous trip
+                    base = self.a_k_o if ks & 1 else self.a_k_e
+                    p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
+                kf.append(f)
+            for rb in range(2):
+                for ks in range(8):
+                    p.mfma(dt, self.SACC[kh][rb], kf[ks], self.QF[rb][ks], self.SACC[kh][rb] if ks else 0, tag="S")
+            # ---- dP^T = V dO^T
+            vf = []
+            for ks in range(8):
+                f = self.pool()
+                base = self.a_v_o if ks & 1 else self.a_v_e
+                p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="V rows")
+                vf.append(f)
+            for rb in range(2):
+                for ks in range(8):
+                    p.mfma(dt, self.DPACC[kh][rb], vf[ks], self.DOF[rb][ks], self.DPACC[kh][rb] if ks else 0, tag="dP")
+            # ---- P, dS, packed in place
+            for rb in range(2):
+                for v in range(16):
+                    x, y = self.SACC[kh][rb][v], self.DPACC[kh][rb][v]
+                    p.v_fma_f32(x, x, P("c_log2"), self.lse2[rb])
+                    p.v_exp_f32(x, x)
+                    if cls:
+                        c = 32 * kh + (v & 3) + 8 * (v >> 2)
+                        p.v_sub_u32(self.tmp[0], self.v_d[rb], c)
+                        if cls == 2:
+                            p.v_cmp("lt_i32", c, self.v_nsh)
+                            p.v_cndmask(self.v_weff, self.v_w, self.v_2e31)
+                            p.v_cmp("lt_u32", self.tmp[0], self.v_weff)
+                        else:
+                            p.v_cmp("lt_u32", self.tmp[0], self.v_w)
+                        p.v_cndmask(x, 0, x)
+                    p.v_sub_f32(y, y, self.nd[rb])
+                    p.v_mul_f32(y, x, y)
+                for s in range(2):
+                    for j in range(4):
+                        d = self.DPACC[kh][rb]
+                        p.v_cvt_pk(dt, d[4 * s + j], d[8 * s + 2 * j], d[8 * s + 2 * j + 1])
+        # ---- dQ^T += K^T dS^T (K^T fragments: transposed reads of the K image, rows = keys)
+        for kh in range(2):
+            for s in range(2):
+                for db in range(4):
+                    f = self.pool()
+                    off = 8192 * kh + 512 * db
+                    p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
+                    p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
+                    for rb in range(2):
+                        p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], self.DQ[rb][db], tag="dQ")
+        # first K fragments of the next tile (landed before this trip's barrier)
+        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=96 * 32 - 300)
+        # next trip
+        p.s_add_u32(self.s_it, self.s_it, 1)
+        t0 = st[3]
+        p.s_mov(self.s_st, self.s_stn)
+        p.s_add_u32(t0, self.s_stn, STG_BYTES)
+        p.s_and_b32(self.s_stn, t0, LDS_BYTES - 1)
+        p.s_add_u32(t0, self.s_std, STG_BYTES)
+        p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
+        return p
+
+    # ------------------------------------------------------------------ epilogue
+    def epilogue(self) -> Prog:
+        p = Prog()
+        dt = self.dtype
+        t0, t1, t2, t3 = self.tmp
+        st = self.s_tmp
+        p.label("L_done%=")
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        # dQ[row, d] = scale * dQ^T[d, row]: lane = row, registers 4 g4 + e <-> d = 32 db + 8 g4 + 4 h + e
+        p.s_mul_i32(st[1], self.s_hh, P("dq_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("dq_hs"))
+        p.s_add_u32(self.d_x[0], P("dq_lo"), st[1])
+        p.s_addc_u32(self.d_x[1], P("dq_hi"), st[2])
+        p.s_mov(self.d_x[2], P("dq_rng"))
+        p.s_mov(self.d_x[3], 0x00020000)
+        p.v_sub_u32(t0, self.v_pos[0], P("pos0"))             # row, rb = 0
+        p.v_mul_lo_u32(t1, t0, P("dq_sn"))
+        p.v_lshrrev(t2, 5, self.lane)
+        p.v_lshl_add_u32(self.vo[0], t2, 3, t1)               # + 8 h bytes
+        p.s_lshl_b32(st[1], P("dq_sn"), 5)
+        p.v_add_u32(self.vo[1], st[1], self.vo[0])
+        for rb in range(2):
+            for db in range(4):
+                for g4 in range(4):
+                    regs = self.POOL[(db * 4 + g4) % 8]
+                    for e in range(4):
+                        p.v_accvgpr_read(regs[e], self.DQ[rb][db][4 * g4 + e])
+                    for e in range(4):
+                        p.v_mul_f32(regs[e], P("scale"), regs[e])
+                    p.v_cvt_pk(dt, regs[0], regs[0], regs[1])
+                    p.v_cvt_pk(dt, regs[1], regs[2], regs[3])
+                    p.buffer_store(regs[0:2], self.vo[rb], self.d_x, 0, offset=64 * db + 16 * g4)
+        p.s_waitcnt(vmcnt=0)
+        return p
+
+    def build(self):
+        items = []
+        items += finish_block(self.prologue().items)
+        items += insert_waits(self.loop_top().items)
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")):
+            body = self.tile_body(cls).items
+            items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
+            if self.do_sched:
+                body = schedule(body)
+            body = insert_waits(body)
+            body = fix_hazards(body, loop=True)
+            items += body
+            items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        items += finish_block(self.epilogue().items)
+        return items
+
+    def clobbers(self):
+        c = ["v%d" % i for i in range(self.vfirst, 256)] + ["a%d" % i for i in range(256)]
+        c += ["s%d" % i for i in range(self.sfirst, 100)] + ["vcc", "scc", "memory"]
+        return c

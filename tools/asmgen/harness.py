@@ -95,3 +95,67 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
         t = torch.from_numpy(raw.view(np.int16).copy())
         return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
     return back(adk), back(adv)
+
+
+# ------------------------------------------------------------------------------------------------ dQ kernel
+def dq_block_params(N, Nk, ns, window, g, qt, hpw):
+    """tile list of the workgroup that owns query tile `qt` (BM = 64 * 4 / hpw rows); the shell's arithmetic"""
+    P = Nk - N
+    W = min(max(window, 0), Nk)
+    BM = 64 * (4 // hpw)
+    q0 = qt * BM
+    q1 = min(q0 + BM, N)
+    ns_eff = min(ns, q1 + P)
+    ts_hi = (ns_eff + 63) >> 6
+    wlo = max(q0 + P - W + 1, 0)
+    tw_lo = max(wlo >> 6, ts_hi)
+    tw_hi = (q1 + P + 63) >> 6
+    tw_lo = min(tw_lo, tw_hi)
+    return dict(P=P, W=W, q0=q0, ts_hi=ts_hi, tw_off=tw_lo - ts_hi, nt=ts_hi + (tw_hi - tw_lo), BM=BM)
+
+
+def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, stats=None):
+    """q, do [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; lse, delta [B, Hq, N].  Returns dq [B, Hq, N, D] float32."""
+    from . import dq as KQ
+    B, Hq, N, D = q.shape
+    Hkv, Nk = k.shape[1], k.shape[2]
+    g = Hq // Hkv
+    assert D == 128
+    hpw = math.gcd(g, 4)
+    scale = 1.0 / math.sqrt(D)
+    mem = Memory()
+    aq, ak, av, ado = (mem.alloc(to_u16(t)) for t in (q, k, v, do))
+    alse = mem.alloc(lse.float().contiguous().numpy())
+    adl = mem.alloc(delta.float().contiguous().numpy())
+    adq = mem.alloc_zero(B * Hq * N * D * 2)
+    BM = 64 * (4 // hpw)
+    nqt = (N + BM - 1) // BM
+    for b in range(B):
+        for hk in range(Hkv):
+            for hg in range(g // hpw):
+                for qt in range(nqt):
+                    bp = dq_block_params(N, Nk, ns, window, g, qt, hpw)
+                    head0 = hk * g + hg * hpw
+                    hb = (b * Hq + head0) * N
+                    kb = (b * Hkv + hk) * Nk * D * 2
+                    rng_q = ((N - 1) * D + D) * 2
+                    rng_k = ((Nk - 1) * D + D) * 2
+                    lo = lambda x: x & 0xFFFFFFFF
+                    params = dict(
+                        q_lo=lo(aq + hb * D * 2), q_hi=(aq + hb * D * 2) >> 32, q_hs=N * D * 2, q_sn=D * 2, q_rng=rng_q,
+                        do_lo=lo(ado + hb * D * 2), do_hi=(ado + hb * D * 2) >> 32, do_hs=N * D * 2, do_sn=D * 2, do_rng=rng_q,
+                        dq_lo=lo(adq + hb * D * 2), dq_hi=(adq + hb * D * 2) >> 32, dq_hs=N * D * 2, dq_sn=D * 2, dq_rng=rng_q,
+                        k_lo=lo(ak + kb), k_hi=(ak + kb) >> 32, k_sn=D * 2, k_rng=rng_k,
+                        v_lo=lo(av + kb), v_hi=(av + kb) >> 32, v_sn=D * 2, v_rng=rng_k,
+                        lse_lo=lo(alse + hb * 4), lse_hi=(alse + hb * 4) >> 32, dl_lo=lo(adl + hb * 4), dl_hi=(adl + hb * 4) >> 32,
+                        ld_hs=N * 4, q0=bp["q0"], nrows=N, pos0=bp["P"], W=bp["W"], ns=ns, nt=bp["nt"], ts_hi=bp["ts_hi"],
+                        tw_off=bp["tw_off"], hpw_log2={1: 0, 2: 1, 4: 2}[hpw], c_log2=f32_bits(scale * math.log2(math.e)),
+                        nlog2e=f32_bits(-math.log2(math.e)), scale=f32_bits(scale))
+                    assert set(params) == set(KQ.PARAMS), set(params) ^ set(KQ.PARAMS)
+                    wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+                    wg.run()
+                    if stats is not None:
+                        stats.append({"block": (b, hk, hg, qt), "nt": bp["nt"], "icount": [w.icount for w in wg.waves]})
+    raw = mem.read(adq).view(np.uint16).reshape(B, Hq, N, D)
+    t = torch.from_numpy(raw.view(np.int16).copy())
+    return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
