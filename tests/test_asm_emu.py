@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from asmgen.asmcheck import CLANG, assemble          # noqa: E402
 from asmgen.dkdv import DkdvGen                       # noqa: E402
 from asmgen.dq import DqGen                           # noqa: E402
-from asmgen.harness import run_dkdv, run_dq           # noqa: E402
+from asmgen.fwd import FwdGen                         # noqa: E402
+from asmgen.harness import run_dkdv, run_dq, run_fwd  # noqa: E402
 from oracle import sink_oracle as O                   # noqa: E402
 
 _PROGS = {}
@@ -105,4 +106,44 @@ def test_dq_scheduled_body_equals_program_order_bitwise():
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_dq_body_assembles_for_gfx950(dtype):
     ok, err = assemble(_prog(dtype, True, DqGen))
+    assert ok, err[:4000]
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,Nk,ns,W,dtype,aux,spike", [
+    (1, 4, 1, 300, 300, 4, 100, "bf16", True, False),     # 4 heads x 64 rows, s_aux, sink tile + window tiles, ragged rows
+    (1, 2, 2, 333, 333, 70, 50, "f16", True, False),      # MHA: one head x 256 rows per workgroup; sinks over two tiles
+    (2, 2, 1, 77, 200, 3, 64, "bf16", False, False),      # N_q < N_kv, no s_aux (rows start from m = -inf)
+    (1, 1, 1, 600, 600, 0, 600, "bf16", True, True),      # causal; a spiked key forces a late move of the reference point
+    (1, 2, 1, 40, 40, 4, 1, "bf16", False, False),        # window of one key
+])
+def test_fwd_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype, aux, spike):
+    g = torch.Generator().manual_seed(N + 2)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    q = torch.randn(B, Hq, N, 128, generator=g).to(td)
+    k, v = (torch.randn(B, Hkv, Nk, 128, generator=g).to(td) for _ in range(2))
+    if spike:    # rule 26 of the CDNA guide: the rescale branch needs an input that takes it (row maximum jumps by > 2^8)
+        k[:, :, Nk - 40] = q[:, 0, N - 1] * 3
+    sa = torch.randn(Hq, generator=g) * 0.5 if aux else None
+    o_ref, lse_ref = O.sink_attention_dense(q, k, v, ns, W, sa)
+    o, lse = run_fwd(_prog(dtype, True, FwdGen), q, k, v, ns, W, sa, dtype)
+    assert (o.double() - o_ref).abs().max().item() < (1e-2 if dtype == "bf16" else 2e-3)
+    fin = torch.isfinite(lse_ref)
+    assert (lse.double()[fin] - lse_ref[fin]).abs().max().item() < 5e-3
+    assert (lse[~fin] == float("-inf")).all()
+
+
+def test_fwd_scheduled_body_equals_program_order_bitwise():
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(1, 4, 200, 128, generator=g).bfloat16()
+    k, v = (torch.randn(1, 1, 200, 128, generator=g).bfloat16() for _ in range(2))
+    sa = torch.randn(4, generator=g) * 0.5
+    a = run_fwd(_prog("bf16", False, FwdGen), q, k, v, 4, 70, sa, "bf16")
+    b = run_fwd(_prog("bf16", True, FwdGen), q, k, v, 4, 70, sa, "bf16")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm assembler not installed")
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fwd_body_assembles_for_gfx950(dtype):
+    ok, err = assemble(_prog(dtype, True, FwdGen))
     assert ok, err[:4000]

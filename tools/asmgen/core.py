@@ -162,6 +162,8 @@ class Instr:
             return "s_setprio %d" % m["n"]
         if self.op == "s_memtime":
             return "s_memtime %s" % self.dst[0].text()
+        if self.op == "v_permlane32_swap_b32":
+            return "v_permlane32_swap_b32 %s, %s" % (self.dst[0].text(), self.dst[1].text())
         if k in ("ds_read", "ds_write"):
             ops = [d.text() for d in self.dst] + [s.text() for s in self.src]
             t = "%s %s" % (self.op, ", ".join(ops))
@@ -230,6 +232,18 @@ class Prog:
     def s_min_i32(self, d, a, b, note=""): return self._salu2("s_min_i32", d, a, b, note=note)
     def s_max_i32(self, d, a, b, note=""): return self._salu2("s_max_i32", d, a, b, note=note)
     def s_cselect(self, d, a, b, note=""): return self._salu2("s_cselect_b32", d, a, b, scc=False, note=note, reads_scc=True)
+
+    # 64-bit lane masks: VCC <-> an SGPR pair
+    def s_mov_b64(self, d, a, note=""):
+        assert d.n == 2
+        return self.add(Instr("s_mov_b64", [d], [_op(a)], kind="salu", note=note))
+
+    def s_or_b64(self, d, a, b, note=""):
+        assert d.n == 2
+        return self.add(Instr("s_or_b64", [d], [_op(a), _op(b)], mods={"implicit_w": [("scc", 0)]}, kind="salu", note=note))
+
+    def s_cmp_lg_u64(self, a, b, note=""):
+        return self.add(Instr("s_cmp_lg_u64", [], [_op(a), _op(b)], mods={"implicit_w": [("scc", 0)]}, kind="salu", note=note))
 
     def s_cmp(self, cond, a, b, note=""):
         """cond in lt_i32 le_i32 gt_i32 ge_i32 eq_i32 lg_i32 lt_u32 le_u32 gt_u32 ge_u32 eq_u32 lg_u32"""

@@ -331,8 +331,30 @@ class Workgroup:
         if take:
             w.pc = self.labels[ins.mods["label"]]
 
+    def _rd64(self, w, o):
+        if isinstance(o, Imm):
+            return o.bits()
+        if o.kind == "vcc":
+            return int(sum(1 << i for i in range(64) if w.vcc[i]))
+        if o.kind == "s" and o.n == 2:
+            return int(w.s[o.idx]) | (int(w.s[o.idx + 1]) << 32)
+        raise EmuError("bad 64-bit scalar operand %r" % (o,))
+
+    def _wr64(self, w, d, val):
+        if d.kind == "vcc":
+            w.vcc = np.array([(val >> i) & 1 for i in range(64)], dtype=bool)
+        else:
+            w.s[d.idx] = val & 0xFFFFFFFF
+            w.s[d.idx + 1] = (val >> 32) & 0xFFFFFFFF
+
     def x_salu(self, w, ins):
         op = ins.op
+        if op == "s_mov_b64":
+            self._wr64(w, ins.dst[0], self._rd64(w, ins.src[0])); return
+        if op == "s_or_b64":
+            r = self._rd64(w, ins.src[0]) | self._rd64(w, ins.src[1]); w.scc = int(r != 0); self._wr64(w, ins.dst[0], r); return
+        if op == "s_cmp_lg_u64":
+            w.scc = int(self._rd64(w, ins.src[0]) != self._rd64(w, ins.src[1])); return
         s = [self.rd_s(w, o) for o in ins.src]
         M = 0xFFFFFFFF
         sg = lambda x: x - (1 << 32) if x & 0x80000000 else x
@@ -394,7 +416,9 @@ class Workgroup:
                 a, b = a.view(np.int32), b.view(np.int32)
             elif ty == "f32":
                 a, b = _f32(a), _f32(b)
-            w.vcc = {"lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b, "eq": a == b, "ne": a != b, "lg": a != b}[cond].copy()
+            with np.errstate(invalid="ignore"):
+                w.vcc = {"lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b, "eq": a == b, "ne": a != b, "lg": a != b,
+                         "neq": ~(a == b)}[cond].copy()
             return
         if op == "v_cndmask_b32":
             a, b = self.rd_v(w, ins.src[0]), self.rd_v(w, ins.src[1])

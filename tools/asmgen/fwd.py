@@ -1,0 +1,524 @@
+"""Generator of the hand-placed forward kernel body (gfx950, head dim 128, bf16 / f16).
+
+Replaces _sink_flash_attn_fwd_kernel of the reference (sink_attention/sink_flash_attention.py:93-194); same maths as
+csrc/sfa_fwd_mfma.hip (swapped product, online softmax in the exp2 domain seeded with the s_aux logit, deferred
+rescale), different machine mapping:
+
+  workgroup = 4 waves; wave w = 64 query rows (two 32-row blocks rb) of ONE q head, HPW = gcd(group, 4) heads x 4 / HPW
+  row groups share every 64-key K / V tile through LDS; one wave per SIMD, 512 registers: Q fragments (B operands) in 64
+  accumulator registers, O^T [d, row] in 128, the row sums l in 32.
+  The loop is software-pipelined by one tile; iteration i runs
+      A(i+1)   S^T = K Q^T of the NEXT tile              32 MFMAs  (K row fragments from LDS feed both row blocks)
+      E(i)     p = exp2(c s - m), packed in place         VALU, in the gaps of A(i+1)
+      C(i)     O^T += V^T P^T and l += 1 P^T             40 MFMAs  (V^T by transposed LDS reads; the row sum is one more
+                                                                    MFMA per k-step with an all-ones A operand: no VALU adds)
+      M(i+1)   mask, row maximum, new reference m and the rescale factor alpha of the next tile     VALU, in the gaps of C(i)
+  so the exp / pack work of a tile hides under the next tile's QK^T and the max / bookkeeping under its own PV.  The
+  rescale of O and l by alpha (rare: the reference point moves only when the row maximum grows by more than 2^8) runs
+  out of line at the loop head when any lane of the wave asks for it.  K / V tiles arrive by LDS-DMA three tiles ahead
+  into a 4-deep ring; one s_barrier per tile.  Two copies of the body alternate (the S^T registers of tile i and i+1
+  swap roles), times the mask class of the next tile (full / edge / edge with sink keys / none: last tile).
+"""
+from __future__ import annotations
+
+from .core import A, Imm, Instr, M0, P, PV, Prog, Reg, S, V, VCC, fimm, imm
+from .dkdv import Alloc
+from .sched import finish_block, fix_hazards, insert_waits, schedule
+
+STG_BYTES = 32768
+NSTAGE = 4
+LDS_BYTES = NSTAGE * STG_BYTES
+NEG_INF = 0xFF800000
+
+PARAMS = [
+    "q_lo", "q_hi", "q_hs", "q_sn", "q_rng",
+    "o_lo", "o_hi", "o_hs", "o_sn", "o_rng",
+    "k_lo", "k_hi", "k_sn", "k_rng", "v_lo", "v_hi", "v_sn", "v_rng",
+    "lse_lo", "lse_hi", "ld_hs",
+    "m0_0", "m0_1", "m0_2", "m0_3", "l0",          # initial reference (s_aux log2e or -inf) of the workgroup's heads; l0 = 1 / 0
+    "q0", "nrows", "pos0", "W", "ns", "nt", "ts_hi", "tw_off",
+    "hpw_log2", "c_log2", "ln2",
+]
+
+
+class FwdGen:
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0):
+        assert dtype in ("bf16", "f16")
+        self.dtype, self.do_sched, self.thr = dtype, sched, thr
+        self.vfirst, self.sfirst = vfirst, sfirst
+        va = self.va = Alloc("v", vfirst, 255)
+        sa = self.sa = Alloc("s", sfirst, 99)
+        # ---------------- VGPRs
+        self.SS = [[[va("s%d_%d%d" % (par, kh, rb), 16, 4) for rb in range(2)] for kh in range(2)] for par in range(2)]
+        self.POOL = [va("pool%d" % i, 4, 4) for i in range(npool)]
+        self.m = [va("m%d" % rb) for rb in range(2)]          # reference point of the running softmax (log2 domain)
+        self.nms = [va("nms%d" % rb) for rb in range(2)]      # -(m, or 0 where m = -inf): the exponent offset
+        self.alpha = [va("alpha%d" % rb) for rb in range(2)]
+        self.lane, self.lane31 = va("lane"), va("lane31")
+        self.l_row_e, self.l_tr0 = va("l_row_e"), va("l_tr0")
+        self.a_k_e, self.a_k_o = va("a_k_e"), va("a_k_o")
+        self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
+        self.l_dma = [[va("l_dma%d%s" % (e, t)) for t in "kv"] for e in range(2)]
+        self.vt = [va("vt%d" % i) for i in range(2)]
+        self.v_pos = [va("v_pos%d" % rb) for rb in range(2)]
+        self.v_d = [va("v_d%d" % rb) for rb in range(2)]
+        self.v_w, self.v_2e31, self.v_nsh, self.v_weff, self.v_ninf = va("v_w"), va("v_2e31"), va("v_nsh"), va("v_weff"), va("v_ninf")
+        self.tmp = [va("tmp%d" % i) for i in range(6)]
+        self.vo = [va("vo%d" % rb) for rb in range(2)]
+        # ---------------- AGPRs
+        self.QF = [[A((rb * 8 + ks) * 4, 4) for ks in range(8)] for rb in range(2)]
+        self.LACC = [A(64 + rb * 16, 16) for rb in range(2)]
+        self.ONES = A(96, 4)
+        self.OACC = [[A(128 + (rb * 4 + db) * 16, 16) for db in range(4)] for rb in range(2)]
+        # ---------------- SGPRs
+        self.d_k, self.d_v, self.d_x = sa("d_k", 4, 4), sa("d_v", 4, 4), sa("d_x", 4, 4)
+        self.s_flag = sa("s_flag", 2, 2)
+        self.s_f0 = sa("s_f0", 2, 2)
+        self.s_wave, self.s_hh, self.s_rgi = sa("s_wave"), sa("s_hh"), sa("s_rgi")
+        self.s_pw0, self.s_pwhi = sa("s_pw0"), sa("s_pwhi")
+        self.s_it, self.s_k0n = sa("s_it"), sa("s_k0n")
+        self.s_st, self.s_stn, self.s_std = sa("s_st"), sa("s_stn"), sa("s_std")
+        self.s_koff, self.s_voff = sa("s_koff"), sa("s_voff")
+        self.s_wofs, self.s_cls = sa("s_wofs"), sa("s_cls")
+        self.s_tmp = [sa("s_tmp%d" % i) for i in range(5)]
+        self.pool_next = 0
+
+    def params(self):
+        return list(PARAMS)
+
+    def pool(self):
+        r = self.POOL[self.pool_next % len(self.POOL)]
+        self.pool_next += 1
+        return r
+
+    # ------------------------------------------------------------------ shared with dq.py (same tile ring)
+    def emit_tile_of(self, p: Prog, dst, it):
+        p.s_add_u32(dst, it, P("tw_off"))
+        p.s_cmp("lt_u32", it, P("ts_hi"))
+        p.s_cselect(dst, it, dst)
+
+    def emit_dma_tile(self, p: Prog, it_reg, spread=False):
+        t = self.s_tmp
+        self.emit_tile_of(p, t[0], it_reg)
+        p.s_lshl_b32(t[0], t[0], 6)
+        p.s_mul_i32(self.s_koff, t[0], P("k_sn"))
+        p.s_mul_i32(self.s_voff, t[0], P("v_sn"))
+        p.s_cmp("lt_u32", it_reg, P("nt"))
+        p.s_cselect(self.d_k[2], P("k_rng"), 0)
+        p.s_cselect(self.d_v[2], P("v_rng"), 0)
+        k = 0
+        for img, desc, off, col in ((0, self.d_k, self.s_koff, 0), (16384, self.d_v, self.s_voff, 1)):
+            for e in range(2):
+                for half in range(2):
+                    vt = self.vt[k & 1]
+                    p.v_add_u32(vt, off, self.l_dma[e][col])
+                    if half:
+                        p.v_add_u32(vt, 128, vt)
+                    if k == 0:
+                        p.s_add_u32(t[1], self.s_std, self.s_wofs)
+                        p.s_mov_m0(t[1])
+                    else:
+                        p.s_add_m0(t[1], img + 2048 * e + 1024 * half)
+                    ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage",))
+                    if spread:
+                        ins.mods["alap"] = 40 + 120 * k
+                    k += 1
+
+    def emit_class(self, p: Prog, k0):
+        """s_cls of the tile starting at key k0: 0 full, 1 edge (no sink key in the tile), 2 edge with sink keys"""
+        t = self.s_tmp
+        p.s_add_u32(t[0], k0, 63)
+        p.s_cmp("le_i32", t[0], self.s_pw0)
+        p.s_cselect(t[1], 1, 0)
+        p.s_cmp("lt_i32", t[0], P("ns"))
+        p.s_cselect(t[2], 1, 0)
+        p.s_sub_i32(t[0], self.s_pwhi, P("W"))
+        p.s_add_i32(t[0], t[0], 1)
+        p.s_cmp("ge_i32", k0, t[0])
+        p.s_cselect(t[0], 1, 0)
+        p.s_or_b32(t[0], t[0], t[2])
+        p.s_and_b32(t[0], t[0], t[1])
+        p.s_cmp("lt_i32", k0, P("ns"))
+        p.s_cselect(t[1], 2, 1)
+        p.s_cmp("lg_u32", t[0], 0)
+        p.s_cselect(self.s_cls, 0, t[1])
+
+    # ------------------------------------------------------------------ phases
+    def emit_A(self, p: Prog, par_next: int, e, o):
+        """S^T of a tile whose K image row-read addresses are e / o: four chains of 8, into SS[par_next]"""
+        dt = self.dtype
+        for kh in range(2):
+            kf = []
+            for ks in range(8):
+                f = self.pool()
+                base = o if ks & 1 else e
+                p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
+                kf.append(f)
+            for rb in range(2):
+                acc = self.SS[par_next][kh][rb]
+                for ks in range(8):
+                    p.mfma(dt, acc, kf[ks], self.QF[rb][ks], acc if ks else 0, tag="S")
+
+    def emit_M(self, p: Prog, par: int, cls: int, k0):
+        """mask (class cls of the tile at key k0), row maximum, new reference point and rescale factor for the tile in
+        SS[par]; sets s_flag (lane mask: some row's reference moved)"""
+        t = self.tmp
+        for rb in range(2):
+            if cls:
+                p.v_lshrrev(t[1], 5, self.lane)
+                p.v_lshlrev(t[1], 2, t[1])
+                p.v_add_u32(t[1], k0, t[1])
+                p.v_sub_u32(self.v_d[rb], self.v_pos[rb], t[1])        # pos - k0 - 4 h
+                if cls == 2 and rb == 0:
+                    p.v_sub_u32(self.v_nsh, P("ns"), t[1])
+                for kh in range(2):
+                    for v in range(16):
+                        x = self.SS[par][kh][rb][v]
+                        c = 32 * kh + (v & 3) + 8 * (v >> 2)
+                        p.v_sub_u32(t[0], self.v_d[rb], c)
+                        if cls == 2:
+                            p.v_cmp("lt_i32", c, self.v_nsh)
+                            p.v_cndmask(self.v_weff, self.v_w, self.v_2e31)
+                            p.v_cmp("lt_u32", t[0], self.v_weff)
+                        else:
+                            p.v_cmp("lt_u32", t[0], self.v_w)
+                        p.v_cndmask(x, self.v_ninf, x)
+            # row maximum over the lane's 32 scores (two trees of max3), then across the two half-waves
+            regs = [self.SS[par][kh][rb][v] for kh in range(2) for v in range(16)]
+            mx, mx2 = t[2], t[3]
+            p.v_max3_f32(mx, regs[0], regs[1], regs[2])
+            p.v_max3_f32(mx2, regs[3], regs[4], regs[5])
+            i = 6
+            while i + 3 < 32:
+                p.v_max3_f32(mx, mx, regs[i], regs[i + 1])
+                p.v_max3_f32(mx2, mx2, regs[i + 2], regs[i + 3])
+                i += 4
+            p.v_max3_f32(mx, mx, regs[30], regs[31])
+            p.v_max_f32(mx, mx, mx2)
+            p.v_mov(mx2, mx)
+            p.v_permlane32_swap(mx, mx2, note="lanes 32..63 of mx <-> lanes 0..31 of mx2: each lane now holds both halves")
+            p.v_max_f32(mx, mx, mx2)
+            # m_cand = max(m, c mx); the reference moves only when it would grow by more than thr (or from -inf)
+            mc, tt = t[4], t[5]
+            p.v_mul_f32(mc, P("c_log2"), mx)
+            p.v_max_f32(mc, mc, self.m[rb])
+            p.v_add_f32(tt, fimm(self.thr), self.m[rb])
+            p.v_cmp("gt_f32", mc, tt)
+            p.v_cndmask(mc, self.m[rb], mc)                            # m_new
+            p.v_cmp("neq_f32", self.v_ninf, mc)
+            p.v_cndmask(tt, 0, mc)                                     # m_safe = m_new, 0 where m_new = -inf
+            p.v_sub_f32(self.alpha[rb], self.m[rb], tt)
+            p.v_exp_f32(self.alpha[rb], self.alpha[rb])
+            p.v_sub_f32(self.nms[rb], 0, tt)
+            p.v_mov(self.m[rb], mc)
+            p.v_cmp("neq_f32", fimm(1.0), self.alpha[rb])
+            if rb == 0:
+                p.s_mov_b64(self.s_f0, VCC)
+            else:
+                p.s_or_b64(self.s_flag, self.s_f0, VCC)
+
+    def emit_E(self, p: Prog, par: int):
+        """p = exp2(c s - m) of the tile in SS[par], packed in place: [kh][rb][4 s + j]"""
+        for rb in range(2):
+            for kh in range(2):
+                acc = self.SS[par][kh][rb]
+                for v in range(16):
+                    p.v_fma_f32(acc[v], acc[v], P("c_log2"), self.nms[rb])
+                    p.v_exp_f32(acc[v], acc[v])
+                for s in range(2):
+                    for j in range(4):
+                        p.v_cvt_pk(self.dtype, acc[4 * s + j], acc[8 * s + 2 * j], acc[8 * s + 2 * j + 1])
+
+    def emit_C(self, p: Prog, par: int):
+        """O^T += V^T P^T, l += 1 P^T for the tile in SS[par] (V image transposed-read addresses a_tr0 / a_tr1)"""
+        dt = self.dtype
+        for rb in range(2):
+            for kh in range(2):
+                for s in range(2):
+                    pf = self.SS[par][kh][rb][4 * s:4 * s + 4]
+                    p.mfma(dt, self.LACC[rb], self.ONES, pf, self.LACC[rb], tag="l")
+                    for db in range(4):
+                        f = self.pool()
+                        off = 16384 + 8192 * kh + 512 * db
+                        p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
+                        p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
+                        p.mfma(dt, self.OACC[rb][db], f, pf, self.OACC[rb][db], tag="PV")
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self) -> Prog:
+        p = Prog()
+        t0, t1, t2, t3 = self.tmp[:4]
+        st = self.s_tmp
+        lane, wv = self.lane, self.s_wave
+        p.v_and(lane, 63, PV("tid"))
+        p.v_lshrrev(t0, 6, PV("tid"))
+        p.v_readfirstlane(wv, t0)
+        p.v_and(self.lane31, 31, lane)
+        p.s_lshl_b32(st[0], 1, P("hpw_log2"))
+        p.s_sub_u32(st[0], st[0], 1)
+        p.s_and_b32(self.s_hh, wv, st[0])
+        p.s_lshr_b32(self.s_rgi, wv, P("hpw_log2"))
+        p.v_lshrrev(t0, 3, self.lane31)
+        p.v_lshlrev(t0, 11, t0)
+        p.v_and(t1, 7, lane)
+        p.v_lshl_add_u32(t0, t1, 6, t0)
+        p.v_bfe_u32(t1, lane, 2, 2)
+        p.v_lshrrev(t2, 5, lane)                              # h
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(self.l_row_e, t1, 4, t0)
+        p.v_bfe_u32(t0, lane, 2, 2)
+        p.v_lshl_add_u32(t0, t2, 2, t0)
+        p.v_lshlrev(t0, 6, t0)
+        p.v_bfe_u32(t1, lane, 4, 1)
+        p.v_bfe_u32(t3, lane, 1, 1)
+        p.v_lshl_add_u32(t1, t1, 1, t3)
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(t0, t1, 4, t0)
+        p.v_and(t1, 1, lane)
+        p.v_lshl_add_u32(self.l_tr0, t1, 3, t0)
+        p.s_lshl_b32(st[0], self.s_rgi, 6)
+        p.s_add_u32(st[0], st[0], P("q0"))                    # qw0
+        p.s_add_u32(self.s_pw0, st[0], P("pos0"))
+        p.s_add_u32(st[1], st[0], 63)
+        p.s_sub_u32(st[2], P("nrows"), 1)
+        p.s_min_i32(st[1], st[1], st[2])
+        p.s_add_u32(self.s_pwhi, st[1], P("pos0"))
+        p.v_add_u32(t0, st[0], self.lane31)                   # row, rb = 0
+        p.v_add_u32(self.v_pos[0], P("pos0"), t0)
+        p.v_add_u32(self.v_pos[1], 32, self.v_pos[0])
+        # ---- Q fragments -> accumulator registers
+        p.s_mul_i32(st[1], self.s_hh, P("q_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("q_hs"))
+        p.s_add_u32(self.d_x[0], P("q_lo"), st[1])
+        p.s_addc_u32(self.d_x[1], P("q_hi"), st[2])
+        p.s_mov(self.d_x[2], P("q_rng"))
+        p.s_mov(self.d_x[3], 0x00020000)
+        p.v_mul_lo_u32(t1, t0, P("q_sn"))
+        p.v_lshl_add_u32(self.vo[0], t2, 4, t1)
+        p.s_lshl_b32(st[1], P("q_sn"), 5)
+        p.v_add_u32(self.vo[1], st[1], self.vo[0])
+        for rb in range(2):
+            for ks in range(8):
+                p.buffer_load(self.QF[rb][ks], self.vo[rb], self.d_x, 0, offset=32 * ks)
+        # ---- softmax state: m = m0 of the wave's head, l = l0, O = 0 ; constants
+        p.s_cmp("eq_u32", self.s_hh, 1)
+        p.s_cselect(st[1], P("m0_1"), P("m0_0"))
+        p.s_cmp("eq_u32", self.s_hh, 2)
+        p.s_cselect(st[1], P("m0_2"), st[1])
+        p.s_cmp("eq_u32", self.s_hh, 3)
+        p.s_cselect(st[1], P("m0_3"), st[1])
+        for rb in range(2):
+            p.v_mov(self.m[rb], st[1])
+            for i in range(16):
+                p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
+            for db in range(4):
+                for i in range(16):
+                    p.v_accvgpr_write(self.OACC[rb][db][i], 0)
+        ones = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
+        p.v_mov(t1, imm(ones))
+        for i in range(4):
+            p.v_accvgpr_write(self.ONES[i], t1)
+        p.v_mov(self.v_w, P("W"))
+        p.v_mov(self.v_2e31, imm(0x80000000))
+        p.v_mov(self.v_ninf, imm(NEG_INF))
+        # ---- K / V streams (as dq.py)
+        for d, nm in ((self.d_k, "k"), (self.d_v, "v")):
+            p.s_mov(d[0], P(nm + "_lo"))
+            p.s_mov(d[1], P(nm + "_hi"))
+            p.s_mov(d[2], P(nm + "_rng"))
+            p.s_mov(d[3], 0x00020000)
+        rr, slot = t0, t1
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.s_lshl_b32(st[0], wv, 4)
+        for e in range(2):
+            p.v_lshrrev(t3, 2, rr)
+            p.v_add_u32(t3, 2 * e, t3)
+            p.v_and(t3, 3, t3)
+            p.v_xor(t3, t3, slot)
+            p.v_lshl_add_u32(t3, t2, 2, t3)
+            p.v_lshlrev(t3, 4, t3)
+            p.s_add_u32(st[1], st[0], 8 * e)
+            p.v_add_u32(self.vt[0], st[1], rr)
+            for col, nm in ((0, "k"), (1, "v")):
+                p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
+                p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+        p.s_lshl_b32(self.s_wofs, wv, 12)
+        for j in range(3):
+            p.s_mov(self.s_std, j * STG_BYTES)
+            p.s_mov(st[3], j)
+            self.emit_dma_tile(p, st[3])
+        p.s_waitcnt(vmcnt=16, note="Q fragments, tile 0 landed (tiles 1, 2 in flight)")
+        p.s_barrier()
+        # ---- pipeline fill: S^T of tile 0 and its softmax bookkeeping (general mask path: any tile class)
+        p.v_mov(self.a_k_e, self.l_row_e)
+        p.v_xor(self.a_k_o, 32, self.a_k_e)
+        self.pool_next = 0
+        self.emit_A(p, 0, self.a_k_e, self.a_k_o)
+        p.s_mov(st[3], 0)
+        self.emit_tile_of(p, st[4], st[3])
+        p.s_lshl_b32(self.s_k0n, st[4], 6)
+        self.emit_M(p, 0, 2, self.s_k0n)
+        p.s_mov(self.s_it, 0)
+        p.s_mov(self.s_st, 0)
+        p.s_mov(self.s_stn, STG_BYTES)
+        p.s_mov(self.s_std, 3 * STG_BYTES)
+        return p
+
+    # ------------------------------------------------------------------ loop head
+    def loop_top(self) -> Prog:
+        p = Prog()
+        t = self.s_tmp
+        p.label("L_top%=")
+        p.s_cmp("ge_u32", self.s_it, P("nt"))
+        p.s_cbranch("scc1", "L_done%=")
+        p.s_cmp_lg_u64(self.s_flag, 0)
+        p.s_cbranch("scc1", "L_rescale%=")
+        p.label("L_top_a%=")
+        # class of the NEXT tile (3 = there is none)
+        p.s_add_u32(t[3], self.s_it, 1)
+        self.emit_tile_of(p, t[4], t[3])
+        p.s_lshl_b32(self.s_k0n, t[4], 6)
+        self.emit_class(p, self.s_k0n)
+        p.s_cmp("lt_u32", t[3], P("nt"))
+        p.s_cselect(self.s_cls, self.s_cls, 3)
+        p.s_and_b32(t[0], self.s_it, 1)
+        p.s_lshl_b32(t[0], t[0], 2)
+        p.s_add_u32(self.s_cls, self.s_cls, t[0], note="4 parity + class")
+        p.s_waitcnt(vmcnt=8, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
+        p.s_barrier()
+        for code in range(7):
+            p.s_cmp("eq_u32", self.s_cls, code)
+            p.s_cbranch("scc1", "L_body%d%%=" % code)
+        p.s_branch("L_body7%=")
+        return p
+
+    def rescale(self) -> Prog:
+        """out of line: O and l of the rows whose reference point moved are multiplied by alpha (1 elsewhere)"""
+        p = Prog()
+        p.label("L_rescale%=")
+        t = self.tmp
+        k = 0
+        for rb in range(2):
+            regs = [self.LACC[rb][i] for i in range(16)] + [self.OACC[rb][db][i] for db in range(4) for i in range(16)]
+            for a in regs:
+                r = t[k % 4]
+                k += 1
+                p.v_accvgpr_read(r, a)
+                p.v_mul_f32(r, self.alpha[rb], r)
+                p.v_accvgpr_write(a, r)
+        p.s_branch("L_top_a%=")
+        return p
+
+    # ------------------------------------------------------------------ one iteration
+    def body(self, par: int, cls_next: int) -> Prog:
+        """par: SS[par] holds tile i (its exp / PV run here), SS[par ^ 1] receives tile i+1; cls_next 0..2, 3 = none"""
+        p = Prog()
+        self.pool_next = 0
+        st = self.s_tmp
+        p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
+        p.v_xor(self.a_k_o, 32, self.a_k_e)
+        p.v_add_u32(self.a_tr0, self.s_st, self.l_tr0)
+        p.v_xor(self.a_tr1, 32, self.a_tr0)
+        p.s_add_u32(st[4], self.s_it, 3)
+        self.emit_dma_tile(p, st[4], spread=True)
+        if cls_next != 3:
+            self.emit_A(p, par ^ 1, self.a_k_e, self.a_k_o)
+        self.emit_E(p, par)
+        self.emit_C(p, par)
+        if cls_next != 3:
+            self.emit_M(p, par ^ 1, cls_next, self.s_k0n)
+        else:
+            p.s_mov_b64(self.s_flag, 0)
+        p.s_add_u32(self.s_it, self.s_it, 1)
+        t0 = st[3]
+        p.s_mov(self.s_st, self.s_stn)
+        p.s_add_u32(t0, self.s_stn, STG_BYTES)
+        p.s_and_b32(self.s_stn, t0, LDS_BYTES - 1)
+        p.s_add_u32(t0, self.s_std, STG_BYTES)
+        p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
+        return p
+
+    # ------------------------------------------------------------------ epilogue
+    def epilogue(self) -> Prog:
+        p = Prog()
+        dt = self.dtype
+        t0, t1, t2, t3, t4, t5 = self.tmp
+        st = self.s_tmp
+        p.label("L_done%=")
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        # O[row, d] = O^T[d, row] / l (l = 0 -> 1), LSE = ln2 (m + log2 l)
+        p.s_mul_i32(st[1], self.s_hh, P("o_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("o_hs"))
+        p.s_add_u32(self.d_x[0], P("o_lo"), st[1])
+        p.s_addc_u32(self.d_x[1], P("o_hi"), st[2])
+        p.s_mov(self.d_x[2], P("o_rng"))
+        p.s_mov(self.d_x[3], 0x00020000)
+        p.v_sub_u32(t0, self.v_pos[0], P("pos0"))             # row, rb = 0
+        p.v_mul_lo_u32(t1, t0, P("o_sn"))
+        p.v_lshrrev(t2, 5, self.lane)
+        p.v_lshl_add_u32(self.vo[0], t2, 3, t1)
+        p.s_lshl_b32(st[1], P("o_sn"), 5)
+        p.v_add_u32(self.vo[1], st[1], self.vo[0])
+        inv = [self.alpha[0], self.alpha[1]]
+        lg = [self.nms[0], self.nms[1]]
+        for rb in range(2):
+            p.v_accvgpr_read(t3, self.LACC[rb][0])
+            p.v_mov(t4, fimm(1.0))
+            p.v_cmp("eq_f32", 0, t3)
+            p.v_cndmask(t3, t3, t4)                           # l = 0 -> 1
+            p.v_rcp_f32(inv[rb], t3)
+            p.v_log_f32(lg[rb], t3)
+            p.v_add_f32(lg[rb], self.m[rb], lg[rb])
+            p.v_mul_f32(lg[rb], P("ln2"), lg[rb])
+        for rb in range(2):
+            for db in range(4):
+                for g4 in range(4):
+                    regs = self.POOL[(db * 4 + g4) % 8]
+                    for e in range(4):
+                        p.v_accvgpr_read(regs[e], self.OACC[rb][db][4 * g4 + e])
+                    for e in range(4):
+                        p.v_mul_f32(regs[e], inv[rb], regs[e])
+                    p.v_cvt_pk(dt, regs[0], regs[0], regs[1])
+                    p.v_cvt_pk(dt, regs[1], regs[2], regs[3])
+                    p.buffer_store(regs[0:2], self.vo[rb], self.d_x, 0, offset=64 * db + 16 * g4)
+        # LSE [head, row] f32: lanes 0..31 (h = 0) of each row block; rows >= nrows fall outside the descriptor
+        p.s_mul_i32(st[1], self.s_hh, P("ld_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("ld_hs"))
+        p.s_add_u32(self.d_x[0], P("lse_lo"), st[1])
+        p.s_addc_u32(self.d_x[1], P("lse_hi"), st[2])
+        p.s_lshl_b32(self.d_x[2], P("nrows"), 2)
+        p.v_lshlrev(t1, 2, t0)
+        p.v_mov(t3, imm(0x7FFFFFF0))
+        p.v_cmp("gt_u32", 32, self.lane)
+        p.v_cndmask(t1, t3, t1)                               # lanes >= 32: out of range
+        p.v_add_u32(t5, 128, t1)
+        p.buffer_store(lg[0], t1, self.d_x, 0)
+        p.buffer_store(lg[1], t5, self.d_x, 0)
+        p.s_waitcnt(vmcnt=0)
+        return p
+
+    def build(self):
+        items = []
+        items += finish_block(self.prologue().items)
+        items += insert_waits(self.loop_top().items)
+        for par in range(2):
+            for cls in range(4):
+                b = self.body(par, cls).items
+                items.append(Instr("label", mods={"label": "L_body%d%%=" % (4 * par + cls)}, kind="label", cost=0))
+                if self.do_sched:
+                    b = schedule(b)
+                b = insert_waits(b)
+                b = fix_hazards(b, loop=True)
+                # every load into a register is consumed inside the body: nothing outstanding at its end
+                items += b
+                items.append(Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 0}))
+                items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        items += finish_block(self.rescale().items)
+        items += finish_block(self.epilogue().items)
+        return items
+
+    def clobbers(self):
+        c = ["v%d" % i for i in range(self.vfirst, 256)] + ["a%d" % i for i in range(256)]
+        c += ["s%d" % i for i in range(self.sfirst, 100)] + ["vcc", "scc", "memory"]
+        return c

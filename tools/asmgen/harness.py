@@ -159,3 +159,55 @@ def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=
     raw = mem.read(adq).view(np.uint16).reshape(B, Hq, N, D)
     t = torch.from_numpy(raw.view(np.int16).copy())
     return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+
+
+# ------------------------------------------------------------------------------------------------ forward kernel
+def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=True, stats=None):
+    """q [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; s_aux [Hq] or None.  Returns o [B, Hq, N, D] float32, lse [B, Hq, N]."""
+    from . import fwd as KF
+    B, Hq, N, D = q.shape
+    Hkv, Nk = k.shape[1], k.shape[2]
+    g = Hq // Hkv
+    assert D == 128
+    hpw = math.gcd(g, 4)
+    scale = 1.0 / math.sqrt(D)
+    log2e = math.log2(math.e)
+    mem = Memory()
+    aq, ak, av = (mem.alloc(to_u16(t)) for t in (q, k, v))
+    ao = mem.alloc_zero(B * Hq * N * D * 2)
+    alse = mem.alloc_zero(B * Hq * N * 4)
+    BM = 64 * (4 // hpw)
+    nqt = (N + BM - 1) // BM
+    for b in range(B):
+        for hk in range(Hkv):
+            for hg in range(g // hpw):
+                for qt in range(nqt):
+                    bp = dq_block_params(N, Nk, ns, window, g, qt, hpw)
+                    head0 = hk * g + hg * hpw
+                    hb = (b * Hq + head0) * N
+                    kb = (b * Hkv + hk) * Nk * D * 2
+                    rng_q = ((N - 1) * D + D) * 2
+                    rng_k = ((Nk - 1) * D + D) * 2
+                    lo = lambda x: x & 0xFFFFFFFF
+                    m0 = [f32_bits(float(s_aux[head0 + i]) * log2e) if (s_aux is not None and i < hpw) else KF.NEG_INF
+                          for i in range(4)]
+                    params = dict(
+                        q_lo=lo(aq + hb * D * 2), q_hi=(aq + hb * D * 2) >> 32, q_hs=N * D * 2, q_sn=D * 2, q_rng=rng_q,
+                        o_lo=lo(ao + hb * D * 2), o_hi=(ao + hb * D * 2) >> 32, o_hs=N * D * 2, o_sn=D * 2, o_rng=rng_q,
+                        k_lo=lo(ak + kb), k_hi=(ak + kb) >> 32, k_sn=D * 2, k_rng=rng_k,
+                        v_lo=lo(av + kb), v_hi=(av + kb) >> 32, v_sn=D * 2, v_rng=rng_k,
+                        lse_lo=lo(alse + hb * 4), lse_hi=(alse + hb * 4) >> 32, ld_hs=N * 4,
+                        m0_0=m0[0], m0_1=m0[1], m0_2=m0[2], m0_3=m0[3], l0=f32_bits(1.0 if s_aux is not None else 0.0),
+                        q0=bp["q0"], nrows=N, pos0=bp["P"], W=bp["W"], ns=ns, nt=bp["nt"], ts_hi=bp["ts_hi"],
+                        tw_off=bp["tw_off"], hpw_log2={1: 0, 2: 1, 4: 2}[hpw], c_log2=f32_bits(scale * log2e),
+                        ln2=f32_bits(math.log(2.0)))
+                    assert set(params) == set(KF.PARAMS), set(params) ^ set(KF.PARAMS)
+                    wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+                    wg.run()
+                    if stats is not None:
+                        stats.append({"block": (b, hk, hg, qt), "nt": bp["nt"], "icount": [w.icount for w in wg.waves]})
+    raw = mem.read(ao).view(np.uint16).reshape(B, Hq, N, D)
+    t = torch.from_numpy(raw.view(np.int16).copy())
+    o = t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+    lse = torch.from_numpy(mem.read(alse).view(np.float32).reshape(B, Hq, N).copy())
+    return o, lse
