@@ -273,21 +273,25 @@ class DqGen:
         p.v_xor(self.a_kn_o, 32, self.a_kn_e)
         self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)
         p.s_mov(self.s_it, 0)
+        self.emit_tile_state(p, self.s_it)
         p.s_mov(self.s_st, 0)
         p.s_mov(self.s_stn, STG_BYTES)
         p.s_mov(self.s_std, 3 * STG_BYTES)
         return p
 
     # ------------------------------------------------------------------ loop head
+    def emit_tile_state(self, p: Prog, it):
+        """first key and mask class of the tile of iteration `it`"""
+        t = self.s_tmp
+        self.emit_tile_of(p, t[3], it)
+        p.s_lshl_b32(self.s_k0, t[3], 6)
+        self.emit_class(p)
+
     def loop_top(self) -> Prog:
         p = Prog()
-        t = self.s_tmp
         p.label("L_top%=")
         p.s_cmp("ge_u32", self.s_it, P("nt"))
         p.s_cbranch("scc1", "L_done%=")
-        self.emit_tile_of(p, t[0], self.s_it)
-        p.s_lshl_b32(self.s_k0, t[0], 6)
-        self.emit_class(p)
         p.s_waitcnt(vmcnt=8, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last trip")
@@ -388,6 +392,7 @@ class DqGen:
         p.s_and_b32(self.s_stn, t0, LDS_BYTES - 1)
         p.s_add_u32(t0, self.s_std, STG_BYTES)
         p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
+        self.emit_tile_state(p, self.s_it)      # of the next trip (the masks above read the current k0 first)
         return p
 
     # ------------------------------------------------------------------ epilogue

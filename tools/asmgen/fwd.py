@@ -218,9 +218,10 @@ class FwdGen:
                 p.s_or_b64(self.s_flag, self.s_f0, VCC)
 
     def emit_E(self, p: Prog, par: int):
-        """p = exp2(c s - m) of the tile in SS[par], packed in place: [kh][rb][4 s + j]"""
-        for rb in range(2):
-            for kh in range(2):
+        """p = exp2(c s - m) of the tile in SS[par], packed in place: [kh][rb][4 s + j]; key half 0 of both row blocks
+        first (the PV of that half starts while the second half is still being exponentiated)"""
+        for kh in range(2):
+            for rb in range(2):
                 acc = self.SS[par][kh][rb]
                 for v in range(16):
                     p.v_fma_f32(acc[v], acc[v], P("c_log2"), self.nms[rb])
@@ -230,19 +231,36 @@ class FwdGen:
                         p.v_cvt_pk(self.dtype, acc[4 * s + j], acc[8 * s + 2 * j], acc[8 * s + 2 * j + 1])
 
     def emit_C(self, p: Prog, par: int):
-        """O^T += V^T P^T, l += 1 P^T for the tile in SS[par] (V image transposed-read addresses a_tr0 / a_tr1)"""
+        """O^T += V^T P^T, l += 1 P^T for the tile in SS[par] (V image transposed-read addresses a_tr0 / a_tr1); every
+        V^T fragment feeds both row blocks"""
         dt = self.dtype
-        for rb in range(2):
-            for kh in range(2):
-                for s in range(2):
-                    pf = self.SS[par][kh][rb][4 * s:4 * s + 4]
-                    p.mfma(dt, self.LACC[rb], self.ONES, pf, self.LACC[rb], tag="l")
-                    for db in range(4):
-                        f = self.pool()
-                        off = 16384 + 8192 * kh + 512 * db
-                        p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
-                        p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
-                        p.mfma(dt, self.OACC[rb][db], f, pf, self.OACC[rb][db], tag="PV")
+        for kh in range(2):
+            for s in range(2):
+                pf = [self.SS[par][kh][rb][4 * s:4 * s + 4] for rb in range(2)]
+                for rb in range(2):
+                    p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
+                for db in range(4):
+                    f = self.pool()
+                    off = 16384 + 8192 * kh + 512 * db
+                    p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
+                    p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
+                    for rb in range(2):
+                        p.mfma(dt, self.OACC[rb][db], f, pf[rb], self.OACC[rb][db], tag="PV")
+
+    def emit_next_class(self, p: Prog, it_next):
+        """state of the trip that processes tile it_next in E / C: first key and class of the tile after it (the one
+        that trip computes S^T and the maximum of), folded with the trip's parity into the dispatch code 4 par + class
+        (class 3: there is no next tile)"""
+        t = self.s_tmp
+        p.s_add_u32(t[3], it_next, 1)
+        self.emit_tile_of(p, t[4], t[3])
+        p.s_lshl_b32(self.s_k0n, t[4], 6)
+        self.emit_class(p, self.s_k0n)
+        p.s_cmp("lt_u32", t[3], P("nt"))
+        p.s_cselect(self.s_cls, self.s_cls, 3)
+        p.s_and_b32(t[0], it_next, 1)
+        p.s_lshl_b32(t[0], t[0], 2)
+        p.s_add_u32(self.s_cls, self.s_cls, t[0])
 
     # ------------------------------------------------------------------ prologue
     def prologue(self) -> Prog:
@@ -360,6 +378,7 @@ class FwdGen:
         p.s_lshl_b32(self.s_k0n, st[4], 6)
         self.emit_M(p, 0, 2, self.s_k0n)
         p.s_mov(self.s_it, 0)
+        self.emit_next_class(p, self.s_it)
         p.s_mov(self.s_st, 0)
         p.s_mov(self.s_stn, STG_BYTES)
         p.s_mov(self.s_std, 3 * STG_BYTES)
@@ -367,30 +386,20 @@ class FwdGen:
 
     # ------------------------------------------------------------------ loop head
     def loop_top(self) -> Prog:
+        """common path: exit test, rescale test, wait + barrier, dispatch (the full-tile bodies are tested first)"""
         p = Prog()
-        t = self.s_tmp
         p.label("L_top%=")
         p.s_cmp("ge_u32", self.s_it, P("nt"))
         p.s_cbranch("scc1", "L_done%=")
         p.s_cmp_lg_u64(self.s_flag, 0)
         p.s_cbranch("scc1", "L_rescale%=")
         p.label("L_top_a%=")
-        # class of the NEXT tile (3 = there is none)
-        p.s_add_u32(t[3], self.s_it, 1)
-        self.emit_tile_of(p, t[4], t[3])
-        p.s_lshl_b32(self.s_k0n, t[4], 6)
-        self.emit_class(p, self.s_k0n)
-        p.s_cmp("lt_u32", t[3], P("nt"))
-        p.s_cselect(self.s_cls, self.s_cls, 3)
-        p.s_and_b32(t[0], self.s_it, 1)
-        p.s_lshl_b32(t[0], t[0], 2)
-        p.s_add_u32(self.s_cls, self.s_cls, t[0], note="4 parity + class")
         p.s_waitcnt(vmcnt=8, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
         p.s_barrier()
-        for code in range(7):
+        for code in (0, 4, 1, 5, 3, 7, 2):
             p.s_cmp("eq_u32", self.s_cls, code)
             p.s_cbranch("scc1", "L_body%d%%=" % code)
-        p.s_branch("L_body7%=")
+        p.s_branch("L_body6%=")
         return p
 
     def rescale(self) -> Prog:
@@ -437,6 +446,7 @@ class FwdGen:
         p.s_and_b32(self.s_stn, t0, LDS_BYTES - 1)
         p.s_add_u32(t0, self.s_std, STG_BYTES)
         p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
+        self.emit_next_class(p, self.s_it)
         return p
 
     # ------------------------------------------------------------------ epilogue
