@@ -64,13 +64,15 @@ class Alloc:
 
 
 class DkdvGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.do_sched = sched
         self.stamps = stamps            # diagnostic build: s_memtime around the loop head, sums stored per workgroup
+        self.dma_t0, self.dma_dt = dma_t0, dma_dt
+        self.ablate = set(ablate)       # timing-only builds (wrong results): parts of the trip left out, see trip_body
         if stamps:
-            npool = min(npool, 11)
+            npool = min(npool, 10 if stamps == "phases" else 11)
         self.va = Alloc("v", vfirst, 255)
         self.sa = Alloc("s", sfirst, 99)      # s100 / s101 are reserved by the compiler
         self.vfirst, self.sfirst = vfirst, sfirst
@@ -123,15 +125,26 @@ class DkdvGen:
         self.s_tmp = [sa("s_tmp%d" % i) for i in range(4)]
         self.pool_next = 0
         if stamps:
-            self.v_sum = [va("sum_top"), va("sum_body"), va("sum_n")]
+            self.v_sum = [va("sum_top"), va("sum_body"), va("sum_n")] + \
+                ([va("sum_ph%d" % i) for i in range(4)] if stamps == "phases" else [])
             self.s_ta, self.s_tb = self.d_x[0:2], self.d_x[2:4]      # the prologue / epilogue descriptor is idle in the loop
 
     def params(self):
         return PARAMS + (["dbg_lo", "dbg_hi", "bid"] if self.stamps else [])
 
     def emit_stamp(self, p: Prog, dst):
-        p.add(Instr("s_memtime", [dst], [], kind="misc"))
+        p.add(Instr("s_memtime", [dst], [], kind="fence"))
         p.s_waitcnt(lgkmcnt=0)
+
+    def emit_phase_stamp(self, p: Prog, k: int):
+        """diagnostic builds (stamps="phases"): a fenced s_memtime between the four MFMA phases of a trip; the time since
+        the previous stamp is added to sum k (the phases cannot overlap in such a build: read shares, not lengths)"""
+        if self.stamps != "phases":
+            return
+        self.emit_stamp(p, self.s_ta)
+        p.s_sub_u32(self.s_tmp[3], self.s_ta[0], self.s_tb[0])
+        p.v_add_u32(self.v_sum[k], self.s_tmp[3], self.v_sum[k])
+        p.s_mov(self.s_tb[0], self.s_ta[0])
 
     # ------------------------------------------------------------------ helpers
     def pool(self):
@@ -141,9 +154,11 @@ class DkdvGen:
 
     # LDS-DMA of one slice (Q, dO, row constants) into ring stage s_std / s_cstd, with the running source offsets
     def emit_dma_issue(self, p: Prog, spread: bool = False):
-        """`spread`: inside a trip the five pieces get early, staggered deadlines (one per ~4 MFMAs of the S chains, where
-        the gaps carry little else), so that the fetch is three trips ahead of its use in time as well"""
-        dl = (lambda i: {"alap": 40 + 130 * i}) if spread else (lambda i: {})
+        """`spread`: inside a trip the five pieces get early, staggered deadlines (dma_t0 + i dma_dt cycles), so that the
+        fetch is three trips ahead of its use in time as well.  A piece costs ~60 cycles of issue wherever it sits
+        (fenced phase stamps: the S-chain phase, which carries them, takes 859 cycles against 512 of MFMA); placing them
+        in the dV / dK half instead measured 0.7 % slower."""
+        dl = (lambda i: {"alap": self.dma_t0 + self.dma_dt * i}) if spread else (lambda i: {})
         p.s_add_m0(self.s_std, self.s_wofs, note="Q piece 0 of this wave")
         p.buffer_load_lds(16, self.vo_q[0], self.d_q, 0, mem=("dma_stage",)).mods.update(dl(0))
         p.s_add_m0(M0, 1024)
@@ -220,7 +235,7 @@ class DkdvGen:
                 p.ds_read_b128(self.SACC[kbi][4 * g4:4 * g4 + 4], self.a_cn, 32 * g4, mem=("stage_r",))
         if deadline is not None:
             for k, it in enumerate(p.items[n0:]):
-                it.mods["alap"] = deadline + 6 * k
+                it.mods["alap"] = deadline + 26 * k      # one per MFMA slot or so: no burst on the shared LDS
 
     def emit_qrow_prefetch(self, p: Prog, e, o):
         for ks in range(8):
@@ -485,6 +500,7 @@ class DkdvGen:
         for kbi in range(2):
             for ks in range(8):
                 p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
+        self.emit_phase_stamp(p, 3)
         if edge:
             p.v_sub_u32(self.v_d[0], self.s_q0p, self.v_kh, note="(q0 + pos0 + 4 h) - key")
             p.v_sub_u32(self.v_d[1], self.v_d[0], 32)
@@ -512,6 +528,7 @@ class DkdvGen:
                 fv = self.pool()
                 p.ds_read_b128(fv, vb, 8192 * kbi + 512 * (ks >> 1), mem=("v_img_r",), note="V rows")
                 p.mfma(dt, self.DPACC[kbi], fa, fv, self.DPACC[kbi], tag="dP")
+        self.emit_phase_stamp(p, 4)
         # ---- dS = P dP', packed IN PLACE into dP registers [kbi][4 s + j] (the S registers are free from here on: the
         #      next trip's initial accumulators go there while this trip's last MFMAs run)
         for kbi in range(2):
@@ -533,8 +550,9 @@ class DkdvGen:
                             p.mfma(dt, self.DV[db][kbi], f, self.PPK[kbi][s], self.DV[db][kbi], tag="dV")
                         else:
                             p.mfma(dt, self.DK[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DK[db][kbi], tag="dK")
+            self.emit_phase_stamp(p, 5 if which == "dV" else 6)
         # operands of the next trip (stage t + 1, landed before this trip's barrier)
-        self.emit_next_prefetch(p, deadline=64 * 32 - 420)
+        self.emit_next_prefetch(p, deadline=64 * 32 - 900)
         # scalar state of the next trip (its class assumes the same q head; a head change redoes it out of line)
         p.s_add_u32(self.s_q0p, self.s_q0p, 32)
         p.s_add_u32(self.s_t, self.s_t, 1)
@@ -553,6 +571,23 @@ class DkdvGen:
         p.s_and_b32(self.s_cstn, t0, 1023)
         p.s_add_u32(t0, self.s_cstd, 256)
         p.s_and_b32(self.s_cstd, t0, 1023)
+        if self.ablate:
+            # knock-out builds for tools/ab.py (what does a trip cost without ...): "dma" the LDS-DMA pieces, "exp" the
+            # v_exp, "valu" all VALU of the softmax / dS part, "vfrag" the V fragment reads, "consts" the row constants,
+            # "tr" the transposed reads, "mfma_s" the S / dP chains, "mfma_acc" the dV / dK MFMAs
+            drop = []
+            for it in p.items:
+                k = it.kind
+                if "dma" in self.ablate and k == "dma": drop.append(it)
+                if "exp" in self.ablate and k == "trans": drop.append(it)
+                if "valu" in self.ablate and (k == "trans" or it.op.startswith(("v_mul_f32", "v_cvt_pk"))): drop.append(it)
+                if "vfrag" in self.ablate and k == "ds_read" and "v_img_r" in it.mem_r: drop.append(it)
+                if "consts" in self.ablate and k == "ds_read" and it.src[0] in (self.a_c, self.a_cn): drop.append(it)
+                if "tr" in self.ablate and it.op == "ds_read_b64_tr_b16": drop.append(it)
+                if "mfma_s" in self.ablate and k == "mfma" and it.tag in ("S", "dP"): drop.append(it)
+                if "mfma_acc" in self.ablate and k == "mfma" and it.tag in ("dV", "dK"): drop.append(it)
+            ids = set(id(x) for x in drop)
+            p.items = [it for it in p.items if id(it) not in ids]
         return p
 
     # ------------------------------------------------------------------ epilogue
@@ -571,7 +606,7 @@ class DkdvGen:
             p.s_add_u32(self.s_tmp[0], self.s_tmp[0], self.s_wave)
             p.s_lshl_b32(self.s_tmp[0], self.s_tmp[0], 4)
             p.s_add_u32(self.d_x[2], self.s_tmp[0], 16, note="records end behind this wave's 16 bytes")
-            for k, r in enumerate(self.v_sum):
+            for k, r in enumerate(self.v_sum[:3] if self.stamps != "phases" else [self.v_sum[i] for i in (3, 4, 5, 6)]):
                 p.v_mov(t0, self.s_tmp[0])
                 p.v_cmp("eq_u32", 0, self.lane)
                 p.v_cndmask(t0, self.v_oob, t0)

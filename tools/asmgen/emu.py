@@ -309,6 +309,9 @@ class Workgroup:
     # ---- kinds
     def x_nop(self, w, ins): pass
 
+    def x_fence(self, w, ins):
+        self.x_misc(w, ins)
+
     def x_misc(self, w, ins):
         if ins.op == "s_memtime":
             w.s[ins.dst[0].idx] = w.icount & 0xFFFFFFFF       # a clock that ticks once per instruction

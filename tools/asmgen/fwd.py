@@ -42,9 +42,11 @@ PARAMS = [
 
 
 class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120):
         assert dtype in ("bf16", "f16")
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
+        # LDS-DMA deadlines inside a trip (early and staggered; placing them in the PV half measured 0.8 % slower)
+        self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.vfirst, self.sfirst = vfirst, sfirst
         va = self.va = Alloc("v", vfirst, 255)
         sa = self.sa = Alloc("s", sfirst, 99)
@@ -121,7 +123,7 @@ class FwdGen:
                         p.s_add_m0(t[1], img + 2048 * e + 1024 * half)
                     ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage",))
                     if spread:
-                        ins.mods["alap"] = 40 + 120 * k
+                        ins.mods["alap"] = self.dma_t0 + self.dma_dt * k
                     k += 1
 
     def emit_class(self, p: Prog, k0):

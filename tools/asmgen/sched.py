@@ -19,11 +19,12 @@ LDS_LAT = 200       # issue -> data under load, modelled (a wait is inserted whe
 MFMA_LAT = 64       # issue -> result readable by a non-MFMA instruction, modelled
 VALU_LAT = 8
 SATURATION_WAITS = False
+LDS_CYCLES_PER_SLOT = 8  # LDS array cycles one wave may use per MFMA slot (b128 read: 4, b64 read: 2); 4 waves share 32
 MAX_LDS_INFLIGHT = 12   # LDS reads a wave keeps in flight (the hardware counter saturates at 15)
 
 
 def _is_fence(it: Instr) -> bool:
-    return it.kind in ("barrier", "label", "branch") or (it.kind == "wait")
+    return it.kind in ("barrier", "label", "branch", "fence") or (it.kind == "wait")
 
 
 def build_deps(items: Sequence[Instr]) -> List[List[int]]:
@@ -139,6 +140,21 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
             lds_inflight.pop(0)
         return len(lds_inflight) < MAX_LDS_INFLIGHT
 
+    # LDS bandwidth share of ONE wave: the four waves of the workgroup run the same schedule in step and share one LDS
+    # (256 B per clock): 2 ds_read_b128 (or 4 ds_read_b64) per wave and MFMA slot saturate it; bursts beyond that stall
+    # the issue of all four waves.  Token bucket: LDS_CYCLES_PER_SLOT array cycles per 32 clocks, bucket of one slot.
+    bucket = [float(LDS_CYCLES_PER_SLOT), 0.0]           # tokens, time of the last update
+
+    def lds_cost(i: int) -> float:
+        return 4.0 if items[i].op == "ds_read_b128" else 2.0
+
+    def lds_tokens(at: float) -> float:
+        return min(float(LDS_CYCLES_PER_SLOT), bucket[0] + (at - bucket[1]) * LDS_CYCLES_PER_SLOT / MFMA_PIPE)
+
+    def lds_take(i: int, at: float):
+        bucket[0] = lds_tokens(at) - lds_cost(i)
+        bucket[1] = at
+
     def data_ready(i: int) -> float:
         tt = 0.0
         for j in deps[i]:
@@ -157,6 +173,7 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
             t = at + it.cost
             if it.kind == "ds_read":
                 lds_inflight.append(at + LDS_LAT)
+                lds_take(i, at)
         out.append(i)
         ready.discard(i)
         for u in users[i]:
@@ -182,6 +199,8 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
                 key = (alap[i], i)
                 fits = dr + items[i].cost <= start + 0.5
                 urgent = alap[i] + slip < start + MFMA_ISSUE      # waiting for the MFMA would make it late
+                if items[i].kind == "ds_read" and lds_tokens(dr) < lds_cost(i) and not urgent:
+                    continue                      # this wave's share of the LDS is used up for now
                 if (fits or urgent) and (best is None or key < best[0]):
                     best = (key, i, dr)
             if best is not None:

@@ -7,7 +7,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/sink-flash-attention-kernel_amd
 rm -f $P/csrc/gen/*.inc $P/build/sfa_bwd_mfma.o $P/build/sfa_fwd_mfma.o
 if [ -n "${1:-}" ]; then
-  if [ "${2:-}" = "stamps" ]; then export ASMGEN_STAMPS=1; fi      # the ALT body carries s_memtime stamps (tools/stamps_dkdv.py)
+  if [ "${2:-}" = "stamps" ]; then export ASMGEN_STAMPS=1; fi
+  if [ "${2:-}" = "phases" ]; then export ASMGEN_STAMPS=phases; fi   # fenced s_memtime between the MFMA phases of a trip      # the ALT body carries s_memtime stamps (tools/stamps_dkdv.py)
   ASMGEN_ALT="$1" ASMGEN_ALT_DQ="${ASMGEN_ALT_DQ:-{\}}" ASMGEN_ALT_FWD="${ASMGEN_ALT_FWD:-{\}}" make -C $P -j8 EXTRA=-DSFA_AB 2>&1 | grep -E "error|Error|asmgen" || true
 else
   make -C $P -j8 2>&1 | grep -E "error|Error|asmgen" || true
