@@ -48,7 +48,7 @@ def main():
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
     dev = "cuda"
     for name in args.cfg.split(","):
-        if not name:
+        if not name or name not in CFG:
             continue
         B, Hq, Hkv, N, D, ns, W, aux = CFG[name]
         torch.manual_seed(42)
