@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--which", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--cfg", default="C3")
+    ap.add_argument("--values", default="0,1", help="the two values of the knob to compare")
     args = ap.parse_args()
     B, Hq, Hkv, N, D, ns, W, aux = CFG[args.cfg]
     dev = "cuda"
@@ -30,10 +31,11 @@ def main():
     v = torch.randn(B, Hkv, N, D, device=dev, dtype=torch.bfloat16).requires_grad_(True)
     do = torch.randn_like(q)
     lib = _native.lib()
-    res = {0: [], 1: []}
+    vals = [int(x) for x in args.values.split(",")]
+    res = {v: [] for v in vals}
     grads = {}
     for r in range(args.rounds + 2):
-        for var in (0, 1):
+        for var in vals:
             lib.sfa_debug_set_variant(args.which, var)
             ev = HipEvents(4)
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -49,8 +51,8 @@ def main():
             grads[var] = (out.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone())
             q.grad = k.grad = v.grad = None
     lib.sfa_debug_set_variant(args.which, 0)
-    same = all(torch.equal(a, b) for a, b in zip(grads[0], grads[1]))
-    for var in (0, 1):
+    same = all(torch.equal(a, b) for a, b in zip(grads[vals[0]], grads[vals[1]]))
+    for var in vals:
         cols = list(zip(*res[var]))
         med = [sorted(c)[len(c) // 2] for c in cols]
         mn = [min(c) for c in cols]

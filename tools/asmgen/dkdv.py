@@ -653,7 +653,8 @@ class DkdvGen:
                 items.append(Instr("label", mods={"label": "L_edge%="}, kind="label", cost=0))
             if self.do_sched:
                 body = schedule(body)
-            body = insert_waits(body, strict_tail=False)
+            if "waits" not in self.ablate:      # (knock-out build: no LDS waits at all, timing only)
+                body = insert_waits(body, strict_tail=False)
             body = fix_hazards(body, loop=True)
             items += body
             items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
