@@ -368,6 +368,32 @@ def test_backward_with_many_kv_groups(B, Hkv):
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
 
+@pytest.mark.parametrize("D,dtype", [(64, torch.bfloat16), (80, torch.bfloat16), (96, torch.float16), (64, torch.float16)])
+def test_hand_placed_kernels_other_head_dims(D, dtype):
+    """head dims 64 / 80 / 96 with a window long enough for the hand-placed kernels (the compiled ones keep the short
+    windows): GQA, sinks, s_aux, ragged N, strided BNHD inputs, against the oracle"""
+    B, Hq, Hkv, N, ns, W = 2, 8, 2, 777, 4, 400
+    g = torch.Generator().manual_seed(D)
+    qs, ks, vs = rand((B, N, Hq, D), g, dtype), rand((B, N, Hkv, D), g, dtype), rand((B, N, Hkv, D), g, dtype)
+    q, k, v = qs.transpose(1, 2), ks.transpose(1, 2), vs.transpose(1, 2)
+    do = rand((B, Hq, N, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    qd, kd, vd = (t.to(DEV).transpose(1, 2).requires_grad_(True) for t in (qs, ks, vs))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+    assert "asm4x64" in _path(), _path()
+    out.backward(do.to(DEV))
+    assert "dkdvasm4x64" in _path() and "dqasm4x64" in _path(), _path()
+    o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
+    dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
+    to = 2e-2 if dtype == torch.bfloat16 else 1e-2
+    assert_close(out, o_r, to, to, "fwd")
+    assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
+    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
+    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+    assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
+
+
 def test_baseline_c4_full_shape():
     """BASELINE.json configs[3] at its REAL shape: gpt-oss-20b sliding layer, bf16, H_q=64, H_kv=8, D=80, N=8192,
     window=128, s_aux, fwd+bwd including ds_aux, against the banded oracle (cheap at W=128)."""

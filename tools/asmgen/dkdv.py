@@ -64,10 +64,15 @@ class Alloc:
 
 
 class DkdvGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125):
-        assert dtype in ("bf16", "f16")
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125, D=128):
+        assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype = dtype
         self.do_sched = sched
+        # head dim: DK k-steps of 16 in the d contractions, DB 32-wide output blocks of dK^T / dV^T, NCH valid 16-byte
+        # chunks per row.  The LDS images keep 256-byte rows for every head dim; chunks >= NCH are fetched through
+        # out-of-range offsets (zeros) when a 128-byte half holds some valid chunks, halves with none are not fetched.
+        self.D, self.DK, self.DB, self.NCH = D, D // 16, (D + 31) // 32, D // 8
+        self.HALVES = 2 if D > 64 else 1
         self.stamps = stamps            # diagnostic build: s_memtime around the loop head, sums stored per workgroup
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.ablate = set(ablate)       # timing-only builds (wrong results): parts of the trip left out, see trip_body
@@ -78,8 +83,8 @@ class DkdvGen:
         self.vfirst, self.sfirst = vfirst, sfirst
         va, sa = self.va, self.sa
         # ---------------- VGPRs
-        self.KF = [[va("kf%d_%d" % (kbi, ks), 4, 4) for ks in range(8)] for kbi in range(2)]
-        self.QROW = [va("qrow%d" % ks, 4, 4) for ks in range(8)]
+        self.KF = [[va("kf%d_%d" % (kbi, ks), 4, 4) for ks in range(self.DK)] for kbi in range(2)]
+        self.QROW = [va("qrow%d" % ks, 4, 4) for ks in range(8)]      # (8 slots for every head dim: two of them double as scratch)
         self.POOL = [va("pool%d" % i, 4, 4) for i in range(npool)]   # streamed MFMA operand fragments (LDS -> here -> MFMA)
         self.SACC = [va("sacc%d" % kbi, 16, 4) for kbi in range(2)]
         self.DPACC = [va("dpacc%d" % kbi, 16, 4) for kbi in range(2)]
@@ -93,7 +98,7 @@ class DkdvGen:
         self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
         self.a_v_e, self.a_v_o = va("a_v_e"), va("a_v_o")
         self.a_c, self.a_cn = va("a_c"), va("a_cn")
-        self.vo_q = [va("vo_q0"), va("vo_q1")]
+        self.vo_q = [va("vo_q0"), va("vo_q1")]      # running source offsets of the wave's pieces (second half: head dims > 64)
         self.vo_d = [va("vo_d0"), va("vo_d1")]
         self.vo_c, self.vo_ce = va("vo_c"), va("vo_ce")
         self.v_oob = va("v_oob")           # a byte offset no descriptor covers
@@ -106,8 +111,8 @@ class DkdvGen:
         self.tmp = [va("tmp0"), self.QROW[6][0], self.QROW[6][1], self.QROW[6][2]]
         self.vo_k = [self.QROW[6][3], self.QROW[7][0]]      # K fragment load / dK, dV store offsets
         # ---------------- AGPRs
-        self.DV = [[A((db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(4)]
-        self.DK = [[A(128 + (db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(4)]
+        self.DV = [[A((db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(self.DB)]
+        self.DKA = [[A(128 + (db * 2 + kbi) * 16, 16) for kbi in range(2)] for db in range(self.DB)]
         # ---------------- SGPRs
         self.d_q, self.d_do, self.d_c = sa("d_q", 4, 4), sa("d_do", 4, 4), sa("d_c", 4, 4)
         self.d_x = sa("d_x", 4, 4)               # K / V / dK / dV descriptor (prologue, epilogue)
@@ -161,12 +166,14 @@ class DkdvGen:
         dl = (lambda i: {"alap": self.dma_t0 + self.dma_dt * i}) if spread else (lambda i: {})
         p.s_add_m0(self.s_std, self.s_wofs, note="Q piece 0 of this wave")
         p.buffer_load_lds(16, self.vo_q[0], self.d_q, 0, mem=("dma_stage",)).mods.update(dl(0))
-        p.s_add_m0(M0, 1024)
-        p.buffer_load_lds(16, self.vo_q[1], self.d_q, 0, mem=("dma_stage",)).mods.update(dl(1))
-        p.s_add_m0(M0, 8192 - 1024, note="dO piece 0")
+        if self.HALVES == 2:
+            p.s_add_m0(M0, 1024)
+            p.buffer_load_lds(16, self.vo_q[1], self.d_q, 0, mem=("dma_stage",)).mods.update(dl(1))
+        p.s_add_m0(M0, 8192 - 1024 * (self.HALVES - 1), note="dO piece 0")
         p.buffer_load_lds(16, self.vo_d[0], self.d_do, 0, mem=("dma_stage",)).mods.update(dl(2))
-        p.s_add_m0(M0, 1024)
-        p.buffer_load_lds(16, self.vo_d[1], self.d_do, 0, mem=("dma_stage",)).mods.update(dl(3))
+        if self.HALVES == 2:
+            p.s_add_m0(M0, 1024)
+            p.buffer_load_lds(16, self.vo_d[1], self.d_do, 0, mem=("dma_stage",)).mods.update(dl(3))
         # row constants: lanes 0..31 -LSE/scale, 32..63 -Delta of rows q0 .. q0+31; rows >= nrows are forced out of range
         # (they read 0: p = exp2(0) stays finite against the zero Q / dO rows, nothing reaches dK / dV)
         p.s_sub_i32(self.s_tmp[0], P("nrows"), self.s_ldrow, note="rows left in the sequence")
@@ -175,12 +182,24 @@ class DkdvGen:
         p.s_mov_m0(self.s_cstd)
         p.buffer_load_lds(4, self.vo_ce, self.d_c, 0, mem=("dma_stage",)).mods.update(dl(4))
 
+    def emit_half1(self, p: Prog, dst, src, cslot, cbl, tmp):
+        """dst = source offset of the lane in the SECOND 128-byte half of its row (src + 128), or an out-of-range offset
+        when that chunk (8 + 4 cbl + cslot) lies beyond the head dim: the LDS image keeps zeros there"""
+        if self.NCH == 16:
+            p.v_add_u32(dst, 128, src)
+            return
+        p.v_lshl_add_u32(tmp, cbl, 2, cslot)
+        p.v_add_u32(dst, 128, src)
+        p.v_cmp("gt_u32", self.NCH - 8, tmp)
+        p.v_cndmask(dst, self.v_oob, dst)
+
     def emit_dma_step(self, p: Prog):
         """advance the source offsets to the next slice of the same head"""
         p.v_add_u32(self.vo_q[0], self.s_stepq, self.vo_q[0])
-        p.v_add_u32(self.vo_q[1], self.s_stepq, self.vo_q[1])
         p.v_add_u32(self.vo_d[0], self.s_stepd, self.vo_d[0])
-        p.v_add_u32(self.vo_d[1], self.s_stepd, self.vo_d[1])
+        if self.HALVES == 2:
+            p.v_add_u32(self.vo_q[1], self.s_stepq, self.vo_q[1])
+            p.v_add_u32(self.vo_d[1], self.s_stepd, self.vo_d[1])
         p.v_add_u32(self.vo_c, 128, self.vo_c)
         p.s_add_u32(self.s_ldq, self.s_ldq, 1)
         p.s_add_u32(self.s_ldrow, self.s_ldrow, 32)
@@ -195,9 +214,10 @@ class DkdvGen:
             p.s_add_u32(d[0], d[0], P(hs))
             p.s_addc_u32(d[1], d[1], 0)
         p.v_sub_u32(self.vo_q[0], self.vo_q[0], self.s_spanq)
-        p.v_sub_u32(self.vo_q[1], self.vo_q[1], self.s_spanq)
         p.v_sub_u32(self.vo_d[0], self.vo_d[0], self.s_spand)
-        p.v_sub_u32(self.vo_d[1], self.vo_d[1], self.s_spand)
+        if self.HALVES == 2:
+            p.v_sub_u32(self.vo_q[1], self.vo_q[1], self.s_spanq)
+            p.v_sub_u32(self.vo_d[1], self.vo_d[1], self.s_spand)
         p.v_sub_u32(self.vo_c, self.vo_c, self.s_spanc)
         p.s_cmp("lt_u32", self.s_ldh, P("g"))
         p.s_cbranch("scc1", lbl_done)
@@ -238,7 +258,7 @@ class DkdvGen:
                 it.mods["alap"] = deadline + 26 * k      # one per MFMA slot or so: no burst on the shared LDS
 
     def emit_qrow_prefetch(self, p: Prog, e, o):
-        for ks in range(8):
+        for ks in range(self.DK):
             base = o if ks & 1 else e
             p.ds_read_b128(self.QROW[ks], base, 512 * (ks >> 1), mem=("stage_r",), note="Q rows, k-step %d" % ks)
 
@@ -251,6 +271,7 @@ class DkdvGen:
         p.v_lshrrev(t0, 6, PV("tid"))
         p.v_readfirstlane(wv, t0)
         p.v_and(self.lane31, 31, lane)
+        p.v_mov(self.v_oob, imm(0x7FFFFFF0))
         # r = lane & 31, h = lane >> 5 ; l_row_e = 2048 (r >> 3) + 64 (r & 7) + 16 (h ^ ((r >> 2) & 3))
         p.v_lshrrev(t0, 3, self.lane31)                       # r >> 3
         p.v_lshlrev(t0, 11, t0)
@@ -312,11 +333,13 @@ class DkdvGen:
             p.v_and(t3, 3, t3)
             p.v_xor(t3, t3, slot)
             p.v_lshl_add_u32(self.vo_k[0], t3, 4, t2)
-            p.v_add_u32(self.vo_k[1], 128, self.vo_k[0])
             p.s_add_m0(self.s_tmp[2], 2048 * rgl)
             p.buffer_load_lds(16, self.vo_k[0], self.d_x, 0, mem=("v_img",))
-            p.s_add_m0(M0, 1024)
-            p.buffer_load_lds(16, self.vo_k[1], self.d_x, 0, mem=("v_img",))
+            if self.HALVES == 2:
+                p.v_lshrrev(self.vo_k[1], 5, lane)
+                self.emit_half1(p, self.vo_k[1], self.vo_k[0], t3, self.vo_k[1], self.vo_ce)
+                p.s_add_m0(M0, 1024)
+                p.buffer_load_lds(16, self.vo_k[1], self.d_x, 0, mem=("v_img",))
             if rgl < 7:
                 p.v_add_u32(t2, self.s_tmp[3], t2)
 
@@ -332,7 +355,7 @@ class DkdvGen:
         p.s_lshl_b32(self.s_tmp[1], P("k_sn"), 5)
         p.v_add_u32(self.vo_k[1], self.s_tmp[1], self.vo_k[0])
         for kbi in range(2):
-            for ks in range(8):
+            for ks in range(self.DK):
                 p.buffer_load(self.KF[kbi][ks], self.vo_k[kbi], self.d_x, 0, offset=32 * ks)
 
         # ---- mask constants: key0 = wave key0 + r ; v_kh = key0 - 4 h ; weff = key < ns ? 2^31 : W
@@ -347,7 +370,6 @@ class DkdvGen:
         p.v_add_u32(t2, 32, t2)
         p.v_cmp("le_u32", P("ns"), t2)
         p.v_cndmask(self.v_weff[1], t0, t3)
-        p.v_mov(self.v_oob, imm(0x7FFFFFF0))
         # wave-level classification constants
         p.s_add_u32(self.s_kw63, self.s_tmp[0], 63)
         p.s_add_u32(self.s_kww, self.s_tmp[0], P("W"))
@@ -372,7 +394,9 @@ class DkdvGen:
         for vo, sn in ((self.vo_q, "q_sn"), (self.vo_d, "do_sn")):
             p.v_mul_lo_u32(vo[0], t2, P(sn))
             p.v_add_u32(vo[0], vo[0], t3)
-            p.v_add_u32(vo[1], 128, vo[0])
+            if self.HALVES == 2:
+                p.v_lshrrev(rr, 4, t3)                            # chunk index inside the half: 4 cbl + (slot ^ x)
+                self.emit_half1(p, vo[1], vo[0], rr, 0, slot)     # (rr / slot are free again: only `row` t2 and t3 live)
         # row constants: lane L < 32 -> -LSE/scale of row q_row0 + L ; L >= 32 -> -Delta of row q_row0 + L - 32
         p.v_add_u32(t2, P("q_row0"), self.lane31)
         p.v_lshlrev(t2, 2, t2)
@@ -397,8 +421,11 @@ class DkdvGen:
         p.label("L_some%=")
 
         # ---- accumulators
-        for i in range(256):
-            p.v_accvgpr_write(A(i), 0)
+        for acc in (self.DV, self.DKA):
+            for db in range(self.DB):
+                for kbi in range(2):
+                    for i in range(16):
+                        p.v_accvgpr_write(acc[db][kbi][i], 0)
 
         # ---- first three slices into stages 0, 1, 2
         for j in range(3):
@@ -407,7 +434,7 @@ class DkdvGen:
             self.emit_dma_headcheck(p, "pro%d" % j)
             self.emit_dma_issue(p)
             self.emit_dma_step(p)
-        p.s_waitcnt(vmcnt=10, note="V image, K fragments, slice 0 landed (slices 1, 2 in flight)")
+        p.s_waitcnt(vmcnt=2 * (2 * self.HALVES + 1), note="V image, K fragments, slice 0 landed (slices 1, 2 in flight)")
         p.s_barrier()
         # operands of the first trip
         p.v_add_u32(self.a_rown_e, STG_BASE, self.l_row_e)
@@ -449,7 +476,7 @@ class DkdvGen:
         p.s_cbranch("scc0", "L_cmphead%=")
         p.label("L_top_b%=")
         p.s_cmp("lg_u32", self.s_full, 0)
-        p.s_waitcnt(vmcnt=5, note="slice t+1 landed (own pieces); slice t+2 may be in flight")
+        p.s_waitcnt(vmcnt=2 * self.HALVES + 1, note="slice t+1 landed (own pieces); slice t+2 may be in flight")
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="S-chain operands of this slice (fetched at the end of the last trip)")
         if self.stamps:      # head time: loop head + waits + barrier
@@ -498,7 +525,7 @@ class DkdvGen:
         # ---- [A] S' = Q K^T - LSE/scale, key block after key block (operands and initial accumulators were fetched
         #      at the end of the previous trip)
         for kbi in range(2):
-            for ks in range(8):
+            for ks in range(self.DK):
                 p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
         self.emit_phase_stamp(p, 3)
         if edge:
@@ -519,7 +546,7 @@ class DkdvGen:
                 for j in range(4):
                     p.v_cvt_pk(dt, self.PPK[kbi][s][j], self.SACC[kbi][8 * s + 2 * j], self.SACC[kbi][8 * s + 2 * j + 1])
         # ---- [B] dP' = dO V^T - Delta, k-step after k-step (dO row fragment shared by the two key blocks)
-        for ks in range(8):
+        for ks in range(self.DK):
             base = self.a_row_o if ks & 1 else self.a_row_e
             fa = self.pool()
             p.ds_read_b128(fa, base, 8192 + 512 * (ks >> 1), mem=("stage_r",), note="dO rows, k-step %d" % ks)
@@ -540,7 +567,7 @@ class DkdvGen:
         # ---- [C] dV^T += dO^T P ; [D] dK^T += Q^T dS   (A operands: transposed reads, rows 16 s + 8 half + ..)
         for which in ("dV", "dK"):
             img = 8192 if which == "dV" else 0
-            for db in range(4):
+            for db in range(self.DB):
                 for s in range(2):
                     f = self.pool()
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, img + 2048 * (2 * s) + 512 * db, mem=("stage_r",))
@@ -549,10 +576,11 @@ class DkdvGen:
                         if which == "dV":
                             p.mfma(dt, self.DV[db][kbi], f, self.PPK[kbi][s], self.DV[db][kbi], tag="dV")
                         else:
-                            p.mfma(dt, self.DK[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DK[db][kbi], tag="dK")
+                            p.mfma(dt, self.DKA[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DKA[db][kbi], tag="dK")
             self.emit_phase_stamp(p, 5 if which == "dV" else 6)
         # operands of the next trip (stage t + 1, landed before this trip's barrier)
-        self.emit_next_prefetch(p, deadline=64 * 32 - 900)
+        n_mfma = 4 * self.DK + 8 * self.DB
+        self.emit_next_prefetch(p, deadline=max(200, n_mfma * 32 - 900))
         # scalar state of the next trip (its class assumes the same q head; a head change redoes it out of line)
         p.s_add_u32(self.s_q0p, self.s_q0p, 32)
         p.s_add_u32(self.s_t, self.s_t, 1)
@@ -618,7 +646,7 @@ class DkdvGen:
         p.v_add_u32(t2, self.s_tmp[0], self.lane31)
         p.v_lshrrev(t3, 5, self.lane)
         p.v_lshlrev(t3, 3, t3)
-        for which, acc in (("dk", self.DK), ("dv", self.DV)):
+        for which, acc in (("dk", self.DKA), ("dv", self.DV)):
             p.s_mov(self.d_x[0], P(which + "_lo"))
             p.s_mov(self.d_x[1], P(which + "_hi"))
             p.s_mov(self.d_x[2], P(which + "_rng"))
@@ -628,8 +656,10 @@ class DkdvGen:
             p.s_lshl_b32(self.s_tmp[1], P(which + "_sn"), 5)
             p.v_add_u32(self.vo_k[1], self.s_tmp[1], self.vo_k[0])
             for kbi in range(2):
-                for db in range(4):
+                for db in range(self.DB):
                     for g4 in range(4):
+                        if 32 * db + 8 * g4 >= self.D:
+                            continue                                        # padding columns of the last block
                         regs = self.POOL[(db * 4 + g4) % 8]                 # 8 staging sets: a set is rewritten 7 stores later
                         for e in range(4):
                             p.v_accvgpr_read(regs[e], acc[db][kbi][4 * g4 + e])

@@ -43,9 +43,13 @@ PARAMS = [
 
 
 class DqGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12):
-        assert dtype in ("bf16", "f16")
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, D=128):
+        assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
+        # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
+        # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
+        self.D, self.DK, self.DB, self.NCH = D, D // 16, (D + 31) // 32, D // 8
+        self.HALVES = 2 if D > 64 else 1
         self.vfirst, self.sfirst = vfirst, sfirst
         va = self.va = Alloc("v", vfirst, 255)
         sa = self.sa = Alloc("s", sfirst, 99)
@@ -61,16 +65,19 @@ class DqGen:
         self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
         self.a_kn_e, self.a_kn_o = va("a_kn_e"), va("a_kn_o")
         self.l_dma = [[va("l_dma%d%s" % (e, t)) for t in "kv"] for e in range(2)]
-        self.vt = [va("vt%d" % i) for i in range(2)]               # DMA source offsets of the piece being issued
+        # second 128-byte half of the rows: an out-of-range offset for lanes whose chunk lies beyond the head dim
+        self.l_dma1 = [[va("l_dma1_%d%s" % (e, t)) for t in "kv"] for e in range(2)] if 64 < D < 128 else None
+        self.vt = [va("vt%d" % i) for i in range(2)]
+        self.v_oob = va("v_oob")               # DMA source offsets of the piece being issued
         self.v_pos = [va("v_pos%d" % rb) for rb in range(2)]       # key position of the lane's row
         self.v_d = [va("v_d%d" % rb) for rb in range(2)]
         self.v_w, self.v_2e31, self.v_nsh, self.v_weff = va("v_w"), va("v_2e31"), va("v_nsh"), va("v_weff")
         self.tmp = [va("tmp%d" % i) for i in range(4)]
         self.vo = [va("vo%d" % rb) for rb in range(2)]             # row offsets (prologue loads, epilogue stores)
         # ---------------- AGPRs
-        self.QF = [[A((rb * 8 + ks) * 4, 4) for ks in range(8)] for rb in range(2)]
-        self.DOF = [[A(64 + (rb * 8 + ks) * 4, 4) for ks in range(8)] for rb in range(2)]
-        self.DQ = [[A(128 + (rb * 4 + db) * 16, 16) for db in range(4)] for rb in range(2)]
+        self.QF = [[A((rb * 8 + ks) * 4, 4) for ks in range(self.DK)] for rb in range(2)]
+        self.DOF = [[A(64 + (rb * 8 + ks) * 4, 4) for ks in range(self.DK)] for rb in range(2)]
+        self.DQ = [[A(128 + (rb * 4 + db) * 16, 16) for db in range(self.DB)] for rb in range(2)]
         # ---------------- SGPRs
         self.d_k, self.d_v, self.d_x = sa("d_k", 4, 4), sa("d_v", 4, 4), sa("d_x", 4, 4)
         self.s_wave, self.s_hh, self.s_rgi = sa("s_wave"), sa("s_hh"), sa("s_rgi")
@@ -113,11 +120,14 @@ class DqGen:
         k = 0
         for img, desc, off, col in ((0, self.d_k, self.s_koff, 0), (16384, self.d_v, self.s_voff, 1)):
             for e in range(2):
-                for half in range(2):
+                for half in range(self.HALVES):
                     vt = self.vt[k & 1]
-                    p.v_add_u32(vt, off, self.l_dma[e][col])
-                    if half:
-                        p.v_add_u32(vt, 128, vt)
+                    if half and self.l_dma1 is not None:
+                        p.v_add_u32(vt, off, self.l_dma1[e][col])
+                    else:
+                        p.v_add_u32(vt, off, self.l_dma[e][col])
+                        if half:
+                            p.v_add_u32(vt, 128, vt)
                     if k == 0:
                         p.s_add_u32(t[1], self.s_std, self.s_wofs)
                         p.s_mov_m0(t[1])
@@ -130,7 +140,7 @@ class DqGen:
 
     def emit_k_prefetch(self, p: Prog, e, o, deadline=None):
         """first four K row fragments (key half 0, k-steps 0..3) of the next tile, into pool slots 0..3"""
-        for ks in range(4):
+        for ks in range(4):      # (DK >= 4 for every supported head dim)
             base = o if ks & 1 else e
             ins = p.ds_read_b128(self.POOL[ks], base, 512 * (ks >> 1), mem=("stage_r",))
             if deadline is not None:
@@ -166,6 +176,7 @@ class DqGen:
         p.v_lshrrev(t0, 6, PV("tid"))
         p.v_readfirstlane(wv, t0)
         p.v_and(self.lane31, 31, lane)
+        p.v_mov(self.v_oob, imm(0x7FFFF000))
         # wave -> head hh = wave & (HPW - 1), row group rgi = wave >> log2(HPW)
         p.s_lshl_b32(st[0], 1, P("hpw_log2"))
         p.s_sub_u32(st[0], st[0], 1)
@@ -214,7 +225,7 @@ class DqGen:
             p.s_lshl_b32(st[1], P(nm + "_sn"), 5)
             p.v_add_u32(self.vo[1], st[1], self.vo[0])
             for rb in range(2):
-                for ks in range(8):
+                for ks in range(self.DK):
                     p.buffer_load(frags[rb][ks], self.vo[rb], self.d_x, 0, offset=32 * ks)
         # ---- row constants: -LSE log2(e) and Delta (rows >= nrows read 0)
         p.s_mul_i32(st[1], self.s_hh, P("ld_hs"))
@@ -256,10 +267,15 @@ class DqGen:
             for col, nm in ((0, "k"), (1, "v")):
                 p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
                 p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+                if self.l_dma1 is not None:      # chunk 8 + (t3 >> 4) of the row must be < NCH
+                    p.v_lshrrev(self.vt[1], 4, t3)
+                    p.v_add_u32(self.l_dma1[e][col], 128, self.l_dma[e][col])
+                    p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
+                    p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
         p.s_lshl_b32(self.s_wofs, wv, 12)                     # 4096 wave: the wave's four pieces inside an image
         # ---- accumulators
         for rb in range(2):
-            for db in range(4):
+            for db in range(self.DB):
                 for i in range(16):
                     p.v_accvgpr_write(self.DQ[rb][db][i], 0)
         # ---- first three tiles into stages 0, 1, 2
@@ -267,7 +283,7 @@ class DqGen:
             p.s_mov(self.s_std, j * STG_BYTES)
             p.s_mov(st[3], j)
             self.emit_dma_tile(p, st[3])
-        p.s_waitcnt(vmcnt=16, note="Q / dO fragments, row constants, tile 0 landed (tiles 1, 2 in flight)")
+        p.s_waitcnt(vmcnt=2 * 4 * self.HALVES, note="Q / dO fragments, row constants, tile 0 landed (tiles 1, 2 in flight)")
         p.s_barrier()
         p.v_mov(self.a_kn_e, self.l_row_e)
         p.v_xor(self.a_kn_o, 32, self.a_kn_e)
@@ -292,7 +308,7 @@ class DqGen:
         p.label("L_top%=")
         p.s_cmp("ge_u32", self.s_it, P("nt"))
         p.s_cbranch("scc1", "L_done%=")
-        p.s_waitcnt(vmcnt=8, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
+        p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last trip")
         p.s_cmp("eq_u32", self.s_cls, 0)
@@ -331,24 +347,24 @@ class DqGen:
         for kh in range(2):
             # ---- S^T = K Q^T: the eight K row fragments of this key half feed both row blocks
             kf = []
-            for ks in range(8):
+            for ks in range(self.DK):
                 f = self.pool()
                 if not (kh == 0 and ks < 4):          # the first four were fetched at the end of the previous trip
                     base = self.a_k_o if ks & 1 else self.a_k_e
                     p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
                 kf.append(f)
             for rb in range(2):
-                for ks in range(8):
+                for ks in range(self.DK):
                     p.mfma(dt, self.SACC[kh][rb], kf[ks], self.QF[rb][ks], self.SACC[kh][rb] if ks else 0, tag="S")
             # ---- dP^T = V dO^T
             vf = []
-            for ks in range(8):
+            for ks in range(self.DK):
                 f = self.pool()
                 base = self.a_v_o if ks & 1 else self.a_v_e
                 p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="V rows")
                 vf.append(f)
             for rb in range(2):
-                for ks in range(8):
+                for ks in range(self.DK):
                     p.mfma(dt, self.DPACC[kh][rb], vf[ks], self.DOF[rb][ks], self.DPACC[kh][rb] if ks else 0, tag="dP")
             # ---- P, dS, packed in place
             for rb in range(2):
@@ -375,7 +391,7 @@ class DqGen:
         # ---- dQ^T += K^T dS^T (K^T fragments: transposed reads of the K image, rows = keys)
         for kh in range(2):
             for s in range(2):
-                for db in range(4):
+                for db in range(self.DB):
                     f = self.pool()
                     off = 8192 * kh + 512 * db
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
@@ -383,7 +399,7 @@ class DqGen:
                     for rb in range(2):
                         p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], self.DQ[rb][db], tag="dQ")
         # first K fragments of the next tile (landed before this trip's barrier)
-        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=96 * 32 - 300)
+        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=(8 * self.DK + 8 * self.DB) * 32 - 300)
         # next trip
         p.s_add_u32(self.s_it, self.s_it, 1)
         t0 = st[3]
@@ -417,8 +433,10 @@ class DqGen:
         p.s_lshl_b32(st[1], P("dq_sn"), 5)
         p.v_add_u32(self.vo[1], st[1], self.vo[0])
         for rb in range(2):
-            for db in range(4):
+            for db in range(self.DB):
                 for g4 in range(4):
+                    if 32 * db + 8 * g4 >= self.D:
+                        continue                              # padding columns of the last block
                     regs = self.POOL[(db * 4 + g4) % 8]
                     for e in range(4):
                         p.v_accvgpr_read(regs[e], self.DQ[rb][db][4 * g4 + e])

@@ -42,9 +42,13 @@ PARAMS = [
 
 
 class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120):
-        assert dtype in ("bf16", "f16")
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128):
+        assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
+        # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
+        # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
+        self.D, self.DK, self.DB, self.NCH = D, D // 16, (D + 31) // 32, D // 8
+        self.HALVES = 2 if D > 64 else 1
         # LDS-DMA deadlines inside a trip (early and staggered; placing them in the PV half measured 0.8 % slower)
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.vfirst, self.sfirst = vfirst, sfirst
@@ -61,17 +65,20 @@ class FwdGen:
         self.a_k_e, self.a_k_o = va("a_k_e"), va("a_k_o")
         self.a_tr0, self.a_tr1 = va("a_tr0"), va("a_tr1")
         self.l_dma = [[va("l_dma%d%s" % (e, t)) for t in "kv"] for e in range(2)]
+        # second 128-byte half of the rows: an out-of-range offset for lanes whose chunk lies beyond the head dim
+        self.l_dma1 = [[va("l_dma1_%d%s" % (e, t)) for t in "kv"] for e in range(2)] if 64 < D < 128 else None
         self.vt = [va("vt%d" % i) for i in range(2)]
+        self.v_oob = va("v_oob")
         self.v_pos = [va("v_pos%d" % rb) for rb in range(2)]
         self.v_d = [va("v_d%d" % rb) for rb in range(2)]
         self.v_w, self.v_2e31, self.v_nsh, self.v_weff, self.v_ninf = va("v_w"), va("v_2e31"), va("v_nsh"), va("v_weff"), va("v_ninf")
         self.tmp = [va("tmp%d" % i) for i in range(6)]
         self.vo = [va("vo%d" % rb) for rb in range(2)]
         # ---------------- AGPRs
-        self.QF = [[A((rb * 8 + ks) * 4, 4) for ks in range(8)] for rb in range(2)]
+        self.QF = [[A((rb * 8 + ks) * 4, 4) for ks in range(self.DK)] for rb in range(2)]
         self.LACC = [A(64 + rb * 16, 16) for rb in range(2)]
         self.ONES = A(96, 4)
-        self.OACC = [[A(128 + (rb * 4 + db) * 16, 16) for db in range(4)] for rb in range(2)]
+        self.OACC = [[A(128 + (rb * 4 + db) * 16, 16) for db in range(self.DB)] for rb in range(2)]
         # ---------------- SGPRs
         self.d_k, self.d_v, self.d_x = sa("d_k", 4, 4), sa("d_v", 4, 4), sa("d_x", 4, 4)
         self.s_flag = sa("s_flag", 2, 2)
@@ -111,11 +118,14 @@ class FwdGen:
         k = 0
         for img, desc, off, col in ((0, self.d_k, self.s_koff, 0), (16384, self.d_v, self.s_voff, 1)):
             for e in range(2):
-                for half in range(2):
+                for half in range(self.HALVES):
                     vt = self.vt[k & 1]
-                    p.v_add_u32(vt, off, self.l_dma[e][col])
-                    if half:
-                        p.v_add_u32(vt, 128, vt)
+                    if half and self.l_dma1 is not None:
+                        p.v_add_u32(vt, off, self.l_dma1[e][col])
+                    else:
+                        p.v_add_u32(vt, off, self.l_dma[e][col])
+                        if half:
+                            p.v_add_u32(vt, 128, vt)
                     if k == 0:
                         p.s_add_u32(t[1], self.s_std, self.s_wofs)
                         p.s_mov_m0(t[1])
@@ -151,14 +161,14 @@ class FwdGen:
         dt = self.dtype
         for kh in range(2):
             kf = []
-            for ks in range(8):
+            for ks in range(self.DK):
                 f = self.pool()
                 base = o if ks & 1 else e
                 p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
                 kf.append(f)
             for rb in range(2):
                 acc = self.SS[par_next][kh][rb]
-                for ks in range(8):
+                for ks in range(self.DK):
                     p.mfma(dt, acc, kf[ks], self.QF[rb][ks], acc if ks else 0, tag="S")
 
     def emit_M(self, p: Prog, par: int, cls: int, k0):
@@ -241,7 +251,7 @@ class FwdGen:
                 pf = [self.SS[par][kh][rb][4 * s:4 * s + 4] for rb in range(2)]
                 for rb in range(2):
                     p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
-                for db in range(4):
+                for db in range(self.DB):
                     f = self.pool()
                     off = 16384 + 8192 * kh + 512 * db
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
@@ -274,6 +284,7 @@ class FwdGen:
         p.v_lshrrev(t0, 6, PV("tid"))
         p.v_readfirstlane(wv, t0)
         p.v_and(self.lane31, 31, lane)
+        p.v_mov(self.v_oob, imm(0x7FFFF000))
         p.s_lshl_b32(st[0], 1, P("hpw_log2"))
         p.s_sub_u32(st[0], st[0], 1)
         p.s_and_b32(self.s_hh, wv, st[0])
@@ -318,7 +329,7 @@ class FwdGen:
         p.s_lshl_b32(st[1], P("q_sn"), 5)
         p.v_add_u32(self.vo[1], st[1], self.vo[0])
         for rb in range(2):
-            for ks in range(8):
+            for ks in range(self.DK):
                 p.buffer_load(self.QF[rb][ks], self.vo[rb], self.d_x, 0, offset=32 * ks)
         # ---- softmax state: m = m0 of the wave's head, l = l0, O = 0 ; constants
         p.s_cmp("eq_u32", self.s_hh, 1)
@@ -331,7 +342,7 @@ class FwdGen:
             p.v_mov(self.m[rb], st[1])
             for i in range(16):
                 p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
-            for db in range(4):
+            for db in range(self.DB):
                 for i in range(16):
                     p.v_accvgpr_write(self.OACC[rb][db][i], 0)
         ones = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
@@ -363,12 +374,17 @@ class FwdGen:
             for col, nm in ((0, "k"), (1, "v")):
                 p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
                 p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+                if self.l_dma1 is not None:      # chunk 8 + (t3 >> 4) of the row must be < NCH
+                    p.v_lshrrev(self.vt[1], 4, t3)
+                    p.v_add_u32(self.l_dma1[e][col], 128, self.l_dma[e][col])
+                    p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
+                    p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
         p.s_lshl_b32(self.s_wofs, wv, 12)
         for j in range(3):
             p.s_mov(self.s_std, j * STG_BYTES)
             p.s_mov(st[3], j)
             self.emit_dma_tile(p, st[3])
-        p.s_waitcnt(vmcnt=16, note="Q fragments, tile 0 landed (tiles 1, 2 in flight)")
+        p.s_waitcnt(vmcnt=2 * 4 * self.HALVES, note="Q fragments, tile 0 landed (tiles 1, 2 in flight)")
         p.s_barrier()
         # ---- pipeline fill: S^T of tile 0 and its softmax bookkeeping (general mask path: any tile class)
         p.v_mov(self.a_k_e, self.l_row_e)
@@ -396,7 +412,7 @@ class FwdGen:
         p.s_cmp_lg_u64(self.s_flag, 0)
         p.s_cbranch("scc1", "L_rescale%=")
         p.label("L_top_a%=")
-        p.s_waitcnt(vmcnt=8, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
+        p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
         p.s_barrier()
         for code in (0, 4, 1, 5, 3, 7, 2):
             p.s_cmp("eq_u32", self.s_cls, code)
@@ -411,7 +427,7 @@ class FwdGen:
         t = self.tmp
         k = 0
         for rb in range(2):
-            regs = [self.LACC[rb][i] for i in range(16)] + [self.OACC[rb][db][i] for db in range(4) for i in range(16)]
+            regs = [self.LACC[rb][i] for i in range(16)] + [self.OACC[rb][db][i] for db in range(self.DB) for i in range(16)]
             for a in regs:
                 r = t[k % 4]
                 k += 1
@@ -484,8 +500,10 @@ class FwdGen:
             p.v_add_f32(lg[rb], self.m[rb], lg[rb])
             p.v_mul_f32(lg[rb], P("ln2"), lg[rb])
         for rb in range(2):
-            for db in range(4):
+            for db in range(self.DB):
                 for g4 in range(4):
+                    if 32 * db + 8 * g4 >= self.D:
+                        continue                              # padding columns of the last block
                     regs = self.POOL[(db * 4 + g4) % 8]
                     for e in range(4):
                         p.v_accvgpr_read(regs[e], self.OACC[rb][db][4 * g4 + e])

@@ -46,7 +46,6 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
     B, Hq, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
     g = Hq // Hkv
-    assert D == 128
     scale = 1.0 / math.sqrt(D)
     mem = Memory()
     aq, ak, av, ado = (mem.alloc(to_u16(t)) for t in (q, k, v, do))
@@ -120,7 +119,6 @@ def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=
     B, Hq, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
     g = Hq // Hkv
-    assert D == 128
     hpw = math.gcd(g, 4)
     scale = 1.0 / math.sqrt(D)
     mem = Memory()
@@ -168,7 +166,6 @@ def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=Tru
     B, Hq, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
     g = Hq // Hkv
-    assert D == 128
     hpw = math.gcd(g, 4)
     scale = 1.0 / math.sqrt(D)
     log2e = math.log2(math.e)
