@@ -535,7 +535,8 @@ class DkdvGen:
         for kbi in range(2):
             for v in range(16):
                 x = self.SACC[kbi][v]
-                p.v_mul_f32(x, P("c_log2"), x)
+                if "mulc" not in self.ablate:
+                    p.v_mul_f32(x, P("c_log2"), x)
                 p.v_exp_f32(x, x)
                 if edge:
                     o = (v & 3) + 8 * (v >> 2)
@@ -640,12 +641,13 @@ class DkdvGen:
                 p.v_cndmask(t0, self.v_oob, t0)
                 p.buffer_store(r, t0, self.d_x, 0, offset=4 * k)
             p.s_waitcnt(vmcnt=0)
-        # store offsets: key (block kbi) * row stride + 8 h bytes ; d = 32 db + 8 g4 + 4 h -> immediate 64 db + 16 g4
+        # store offsets: key (block kbi) * row stride + 16 h bytes ; immediate 64 db + 32 gp for the pair of column groups
         p.s_lshl_b32(self.s_tmp[0], self.s_wave, 6)
         p.s_add_u32(self.s_tmp[0], self.s_tmp[0], P("kb0"))
         p.v_add_u32(t2, self.s_tmp[0], self.lane31)
         p.v_lshrrev(t3, 5, self.lane)
-        p.v_lshlrev(t3, 3, t3)
+        p.v_lshlrev(t3, 4, t3)
+        npair = 0
         for which, acc in (("dk", self.DKA), ("dv", self.DV)):
             p.s_mov(self.d_x[0], P(which + "_lo"))
             p.s_mov(self.d_x[1], P(which + "_hi"))
@@ -655,20 +657,29 @@ class DkdvGen:
             p.v_add_u32(self.vo_k[0], self.vo_k[0], t3)
             p.s_lshl_b32(self.s_tmp[1], P(which + "_sn"), 5)
             p.v_add_u32(self.vo_k[1], self.s_tmp[1], self.vo_k[0])
+            # column groups k / k+1 exchanged between the half-waves: 16 contiguous bytes per lane, one dwordx4 store
+            # per pair (the store tail is issue-bound: T21 of the CDNA guide)
             for kbi in range(2):
                 for db in range(self.DB):
-                    for g4 in range(4):
-                        if 32 * db + 8 * g4 >= self.D:
+                    for gp in range(2):
+                        if 32 * db + 16 * gp >= self.D:
                             continue                                        # padding columns of the last block
-                        regs = self.POOL[(db * 4 + g4) % 8]                 # 8 staging sets: a set is rewritten 7 stores later
+                        X, Y = self.POOL[(2 * npair) % 8], self.POOL[(2 * npair + 1) % 8]
+                        npair += 1
                         for e in range(4):
-                            p.v_accvgpr_read(regs[e], acc[db][kbi][4 * g4 + e])
+                            p.v_accvgpr_read(X[e], acc[db][kbi][8 * gp + e])
+                            p.v_accvgpr_read(Y[e], acc[db][kbi][8 * gp + 4 + e])
                         if which == "dk":
                             for e in range(4):
-                                p.v_mul_f32(regs[e], P("scale"), regs[e])
-                        p.v_cvt_pk(dt, regs[0], regs[0], regs[1])
-                        p.v_cvt_pk(dt, regs[1], regs[2], regs[3])
-                        p.buffer_store(regs[0:2], self.vo_k[kbi], self.d_x, 0, offset=64 * db + 16 * g4)
+                                p.v_mul_f32(X[e], P("scale"), X[e])
+                                p.v_mul_f32(Y[e], P("scale"), Y[e])
+                        p.v_cvt_pk(dt, X[0], X[0], X[1])
+                        p.v_cvt_pk(dt, X[1], X[2], X[3])
+                        p.v_cvt_pk(dt, X[2], Y[0], Y[1])
+                        p.v_cvt_pk(dt, X[3], Y[2], Y[3])
+                        p.v_permlane32_swap(X[0], X[2])
+                        p.v_permlane32_swap(X[1], X[3])
+                        p.buffer_store(X[0:4], self.vo_k[kbi], self.d_x, 0, offset=64 * db + 32 * gp)
         p.s_waitcnt(vmcnt=0)
         return p
 

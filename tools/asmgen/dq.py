@@ -43,9 +43,10 @@ PARAMS = [
 
 
 class DqGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, D=128):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, D=128, ablate=()):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
+        self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
         # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
         self.D, self.DK, self.DB, self.NCH = D, D // 16, (D + 31) // 32, D // 8
@@ -370,7 +371,8 @@ class DqGen:
             for rb in range(2):
                 for v in range(16):
                     x, y = self.SACC[kh][rb][v], self.DPACC[kh][rb][v]
-                    p.v_fma_f32(x, x, P("c_log2"), self.lse2[rb])
+                    if "fma" not in self.ablate:
+                        p.v_fma_f32(x, x, P("c_log2"), self.lse2[rb])
                     p.v_exp_f32(x, x)
                     if cls:
                         c = 32 * kh + (v & 3) + 8 * (v >> 2)
@@ -429,22 +431,32 @@ class DqGen:
         p.v_sub_u32(t0, self.v_pos[0], P("pos0"))             # row, rb = 0
         p.v_mul_lo_u32(t1, t0, P("dq_sn"))
         p.v_lshrrev(t2, 5, self.lane)
-        p.v_lshl_add_u32(self.vo[0], t2, 3, t1)               # + 8 h bytes
+        p.v_lshl_add_u32(self.vo[0], t2, 4, t1)               # + 16 h bytes
         p.s_lshl_b32(st[1], P("dq_sn"), 5)
         p.v_add_u32(self.vo[1], st[1], self.vo[0])
+        # groups k / k+1 exchanged between the half-waves: 16 contiguous bytes per lane, one dwordx4 store per pair (as
+        # the forward's epilogue)
+        npair = 0
         for rb in range(2):
             for db in range(self.DB):
-                for g4 in range(4):
-                    if 32 * db + 8 * g4 >= self.D:
+                for gp in range(2):
+                    if 32 * db + 16 * gp >= self.D:
                         continue                              # padding columns of the last block
-                    regs = self.POOL[(db * 4 + g4) % 8]
+                    X, Y = self.POOL[(2 * npair) % 8], self.POOL[(2 * npair + 1) % 8]
+                    npair += 1
                     for e in range(4):
-                        p.v_accvgpr_read(regs[e], self.DQ[rb][db][4 * g4 + e])
+                        p.v_accvgpr_read(X[e], self.DQ[rb][db][8 * gp + e])
+                        p.v_accvgpr_read(Y[e], self.DQ[rb][db][8 * gp + 4 + e])
                     for e in range(4):
-                        p.v_mul_f32(regs[e], P("scale"), regs[e])
-                    p.v_cvt_pk(dt, regs[0], regs[0], regs[1])
-                    p.v_cvt_pk(dt, regs[1], regs[2], regs[3])
-                    p.buffer_store(regs[0:2], self.vo[rb], self.d_x, 0, offset=64 * db + 16 * g4)
+                        p.v_mul_f32(X[e], P("scale"), X[e])
+                        p.v_mul_f32(Y[e], P("scale"), Y[e])
+                    p.v_cvt_pk(dt, X[0], X[0], X[1])
+                    p.v_cvt_pk(dt, X[1], X[2], X[3])
+                    p.v_cvt_pk(dt, X[2], Y[0], Y[1])
+                    p.v_cvt_pk(dt, X[3], Y[2], Y[3])
+                    p.v_permlane32_swap(X[0], X[2])
+                    p.v_permlane32_swap(X[1], X[3])
+                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
         p.s_waitcnt(vmcnt=0)
         return p
 

@@ -42,7 +42,7 @@ PARAMS = [
 
 
 class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128, ablate=(), lsum="mfma"):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
@@ -51,6 +51,8 @@ class FwdGen:
         self.HALVES = 2 if D > 64 else 1
         # LDS-DMA deadlines inside a trip (early and staggered; placing them in the PV half measured 0.8 % slower)
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
+        self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
+        self.lsum_valu = lsum == "valu"   # row sums: f32 adds beside the exponentials ("valu") or ones-MFMAs ("mfma")
         self.vfirst, self.sfirst = vfirst, sfirst
         va = self.va = Alloc("v", vfirst, 255)
         sa = self.sa = Alloc("s", sfirst, 99)
@@ -60,6 +62,8 @@ class FwdGen:
         self.m = [va("m%d" % rb) for rb in range(2)]          # reference point of the running softmax (log2 domain)
         self.nms = [va("nms%d" % rb) for rb in range(2)]      # -(m, or 0 where m = -inf): the exponent offset
         self.alpha = [va("alpha%d" % rb) for rb in range(2)]
+        # per-lane partial row sums (the lane's own keys; the two half-waves are added in the epilogue)
+        self.lsum = [va("lsum%d" % rb) for rb in range(2)] if self.lsum_valu else None
         self.lane, self.lane31 = va("lane"), va("lane31")
         self.l_row_e, self.l_tr0 = va("l_row_e"), va("l_tr0")
         self.a_k_e, self.a_k_o = va("a_k_e"), va("a_k_o")
@@ -236,8 +240,11 @@ class FwdGen:
             for rb in range(2):
                 acc = self.SS[par][kh][rb]
                 for v in range(16):
-                    p.v_fma_f32(acc[v], acc[v], P("c_log2"), self.nms[rb])
+                    if "fma" not in self.ablate:
+                        p.v_fma_f32(acc[v], acc[v], P("c_log2"), self.nms[rb])
                     p.v_exp_f32(acc[v], acc[v])
+                    if self.lsum_valu:
+                        p.v_add_f32(self.lsum[rb], self.lsum[rb], acc[v])
                 for s in range(2):
                     for j in range(4):
                         p.v_cvt_pk(self.dtype, acc[4 * s + j], acc[8 * s + 2 * j], acc[8 * s + 2 * j + 1])
@@ -250,7 +257,8 @@ class FwdGen:
             for s in range(2):
                 pf = [self.SS[par][kh][rb][4 * s:4 * s + 4] for rb in range(2)]
                 for rb in range(2):
-                    p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
+                    if not self.lsum_valu:
+                        p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
                 for db in range(self.DB):
                     f = self.pool()
                     off = 16384 + 8192 * kh + 512 * db
@@ -338,10 +346,16 @@ class FwdGen:
         p.s_cselect(st[1], P("m0_2"), st[1])
         p.s_cmp("eq_u32", self.s_hh, 3)
         p.s_cselect(st[1], P("m0_3"), st[1])
+        if self.lsum_valu:
+            p.v_mov(t1, P("l0"))
+            p.v_cmp("gt_u32", 32, lane)
         for rb in range(2):
             p.v_mov(self.m[rb], st[1])
-            for i in range(16):
-                p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
+            if self.lsum_valu:
+                p.v_cndmask(self.lsum[rb], 0, t1)                 # l0 once per row: lanes 0..31
+            else:
+                for i in range(16):
+                    p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
             for db in range(self.DB):
                 for i in range(16):
                     p.v_accvgpr_write(self.OACC[rb][db][i], 0)
@@ -427,7 +441,11 @@ class FwdGen:
         t = self.tmp
         k = 0
         for rb in range(2):
-            regs = [self.LACC[rb][i] for i in range(16)] + [self.OACC[rb][db][i] for db in range(self.DB) for i in range(16)]
+            regs = [self.OACC[rb][db][i] for db in range(self.DB) for i in range(16)]
+            if self.lsum_valu:
+                p.v_mul_f32(self.lsum[rb], self.alpha[rb], self.lsum[rb])
+            else:
+                regs = [self.LACC[rb][i] for i in range(16)] + regs
             for a in regs:
                 r = t[k % 4]
                 k += 1
@@ -485,13 +503,19 @@ class FwdGen:
         p.v_sub_u32(t0, self.v_pos[0], P("pos0"))             # row, rb = 0
         p.v_mul_lo_u32(t1, t0, P("o_sn"))
         p.v_lshrrev(t2, 5, self.lane)
-        p.v_lshl_add_u32(self.vo[0], t2, 3, t1)
+        p.v_lshl_add_u32(self.vo[0], t2, 4, t1)
         p.s_lshl_b32(st[1], P("o_sn"), 5)
         p.v_add_u32(self.vo[1], st[1], self.vo[0])
         inv = [self.alpha[0], self.alpha[1]]
         lg = [self.nms[0], self.nms[1]]
         for rb in range(2):
-            p.v_accvgpr_read(t3, self.LACC[rb][0])
+            if self.lsum_valu:
+                p.v_mov(t3, self.lsum[rb])
+                p.v_mov(t4, t3)
+                p.v_permlane32_swap(t3, t4)
+                p.v_add_f32(t3, t3, t4)
+            else:
+                p.v_accvgpr_read(t3, self.LACC[rb][0])
             p.v_mov(t4, fimm(1.0))
             p.v_cmp("eq_f32", 0, t3)
             p.v_cndmask(t3, t3, t4)                           # l = 0 -> 1
@@ -499,19 +523,31 @@ class FwdGen:
             p.v_log_f32(lg[rb], t3)
             p.v_add_f32(lg[rb], self.m[rb], lg[rb])
             p.v_mul_f32(lg[rb], P("ln2"), lg[rb])
+        # a lane holds columns 8k .. 8k+3 (half-wave 0) or 8k+4 .. 8k+7 (half-wave 1) of its row for every column group
+        # k: one half exchange per dword between groups k and k+1 leaves 16 contiguous bytes in every lane (lanes 0..31
+        # columns 8k .. 8k+7, lanes 32..63 columns 8k+8 .. 8k+15): half as many store instructions for the same bytes
+        # (the store tail is issue-bound: T21 of the CDNA guide)
+        npair = 0
         for rb in range(2):
             for db in range(self.DB):
-                for g4 in range(4):
-                    if 32 * db + 8 * g4 >= self.D:
+                for gp in range(2):
+                    if 32 * db + 16 * gp >= self.D:
                         continue                              # padding columns of the last block
-                    regs = self.POOL[(db * 4 + g4) % 8]
+                    X, Y = self.POOL[(2 * npair) % 8], self.POOL[(2 * npair + 1) % 8]
+                    npair += 1
                     for e in range(4):
-                        p.v_accvgpr_read(regs[e], self.OACC[rb][db][4 * g4 + e])
+                        p.v_accvgpr_read(X[e], self.OACC[rb][db][8 * gp + e])
+                        p.v_accvgpr_read(Y[e], self.OACC[rb][db][8 * gp + 4 + e])
                     for e in range(4):
-                        p.v_mul_f32(regs[e], inv[rb], regs[e])
-                    p.v_cvt_pk(dt, regs[0], regs[0], regs[1])
-                    p.v_cvt_pk(dt, regs[1], regs[2], regs[3])
-                    p.buffer_store(regs[0:2], self.vo[rb], self.d_x, 0, offset=64 * db + 16 * g4)
+                        p.v_mul_f32(X[e], inv[rb], X[e])
+                        p.v_mul_f32(Y[e], inv[rb], Y[e])
+                    p.v_cvt_pk(dt, X[0], X[0], X[1])
+                    p.v_cvt_pk(dt, X[1], X[2], X[3])
+                    p.v_cvt_pk(dt, X[2], Y[0], Y[1])
+                    p.v_cvt_pk(dt, X[3], Y[2], Y[3])
+                    p.v_permlane32_swap(X[0], X[2])
+                    p.v_permlane32_swap(X[1], X[3])
+                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
         # LSE [head, row] f32: lanes 0..31 (h = 0) of each row block; rows >= nrows fall outside the descriptor
         p.s_mul_i32(st[1], self.s_hh, P("ld_hs"))
         p.s_mul_hi_u32(st[2], self.s_hh, P("ld_hs"))
