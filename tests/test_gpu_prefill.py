@@ -394,6 +394,34 @@ def test_hand_placed_kernels_other_head_dims(D, dtype):
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
 
+@pytest.mark.parametrize("D,dtype,W", [(256, torch.bfloat16, 300), (256, torch.float16, 0), (32, torch.bfloat16, 200),
+                                       (32, torch.float16, 50)])
+def test_mfma_kernels_head_dims_32_and_256(D, dtype, W):
+    """head dims the reference lists beside 64 / 128 (README "Head dims: 64, 128, 256") and a small one: the forward
+    runs the MFMA kernel for both, the backward for 32 (the 256-wide dK / dV accumulators do not fit the MFMA backward:
+    exact-f32 kernels there); GQA, sinks, s_aux, ragged N, against the oracle"""
+    B, Hq, Hkv, N, ns = 2, 4, 2, 333, 4
+    W = W or N
+    g = torch.Generator().manual_seed(D + 1)
+    q, k, v = rand((B, Hq, N, D), g, dtype), rand((B, Hkv, N, D), g, dtype), rand((B, Hkv, N, D), g, dtype)
+    do = rand((B, Hq, N, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    sad = sa.to(DEV).requires_grad_(True)
+    out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+    assert "fwd_mfma" in _path() and "d%d" % D in _path(), _path()
+    out.backward(do.to(DEV))
+    assert ("bwd_mfma" in _path()) == (D == 32), _path()
+    o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
+    dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
+    to = 2e-2 if dtype == torch.bfloat16 else 1e-2
+    assert_close(out, o_r, to, to, "fwd")
+    assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
+    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
+    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+    assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
+
+
 def test_baseline_c4_full_shape():
     """BASELINE.json configs[3] at its REAL shape: gpt-oss-20b sliding layer, bf16, H_q=64, H_kv=8, D=80, N=8192,
     window=128, s_aux, fwd+bwd including ds_aux, against the banded oracle (cheap at W=128)."""

@@ -21,6 +21,8 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "C4b4": (4, 64, 8, 8192, 80, 0, 128, True),
     "D64": (4, 32, 8, 8192, 64, 4, 4096, False),
     "causal": (4, 32, 8, 8192, 128, 0, 8192, False),
+    "D256": (4, 16, 4, 8192, 256, 4, 4096, False),
+    "D32": (4, 32, 8, 8192, 32, 4, 4096, False),
 }
 
 
