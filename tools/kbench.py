@@ -23,6 +23,7 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "causal": (4, 32, 8, 8192, 128, 0, 8192, False),
     "D256": (4, 16, 4, 8192, 256, 4, 4096, False),
     "C2gqa": (4, 32, 8, 4096, 128, 4, 1024, False),
+    "W128d128": (4, 32, 8, 8192, 128, 4, 128, False),
     "D32": (4, 32, 8, 8192, 32, 4, 4096, False),
 }
 
