@@ -85,6 +85,8 @@ def test_stamped_diagnostic_body_runs_and_agrees():
     (1, 2, 2, 333, 333, 70, 50, "f16"),       # MHA: one head x 256 rows per workgroup; sinks over two key tiles
     (2, 2, 1, 77, 200, 3, 64, "bf16"),        # 2 heads x 128 rows; N_q < N_kv
     (1, 2, 1, 40, 40, 4, 1, "bf16"),          # window of one key
+    (1, 1, 1, 700, 700, 4, 192, "bf16"),      # W >= 128: window-edge and causal-edge tiles (typed bodies)
+    (1, 4, 1, 520, 650, 0, 256, "f16"),       # the same with N_q < N_kv and no sinks
 ])
 def test_dq_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype):
     q, k, v, do, lse, delta, _, _ = _case(B, Hq, Hkv, N, Nk, ns, W, dtype, seed=N + 1)
@@ -114,6 +116,8 @@ def test_dq_body_assembles_for_gfx950(dtype):
     (2, 2, 1, 77, 200, 3, 64, "bf16", False, False),      # N_q < N_kv, no s_aux (rows start from m = -inf)
     (1, 1, 1, 600, 600, 0, 600, "bf16", True, True),      # causal; a spiked key forces a late move of the reference point
     (1, 2, 1, 40, 40, 4, 1, "bf16", False, False),        # window of one key
+    (1, 1, 1, 700, 700, 4, 192, "bf16", True, False),     # W >= 128: window-edge and causal-edge tiles take the typed bodies
+    (1, 4, 1, 520, 650, 0, 256, "f16", False, False),     # the same with N_q < N_kv and no sinks
 ])
 def test_fwd_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype, aux, spike):
     g = torch.Generator().manual_seed(N + 2)

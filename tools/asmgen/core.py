@@ -317,6 +317,16 @@ class Prog:
         """d = vcc ? b : a"""
         return self.add(Instr("v_cndmask_b32", [d], [_op(a), _op(b), VCC], kind="valu", note=note))
 
+    def v_cmp_m(self, cond, m, a, b, note=""):
+        """lane mask of (a <cond> b) into the SGPR pair m (VOP3 form: VCC stays free, several masks can be in flight)"""
+        assert m.n == 2
+        return self.add(Instr("v_cmp_%s_e64" % cond, [m], [_op(a), _op(b)], kind="valu", note=note))
+
+    def v_cndmask_m(self, d, a, b, m, note=""):
+        """d = m ? b : a, m an SGPR pair"""
+        assert m.n == 2
+        return self.add(Instr("v_cndmask_b32_e64", [d], [_op(a), _op(b), m], kind="valu", note=note))
+
     def v_accvgpr_write(self, d, a, note=""): return self._valu("v_accvgpr_write_b32", d, [a], note)
     def v_accvgpr_read(self, d, a, note=""): return self._valu("v_accvgpr_read_b32", d, [a], note)
 

@@ -413,16 +413,25 @@ class Workgroup:
     def x_valu(self, w, ins):
         op = ins.op
         if op.startswith("v_cmp_"):
-            cond, ty = op[6:].split("_")
+            cond, ty = op[6:].split("_")[:2]
             a, b = self.rd_v(w, ins.src[0]), self.rd_v(w, ins.src[1])
             if ty == "i32":
                 a, b = a.view(np.int32), b.view(np.int32)
             elif ty == "f32":
                 a, b = _f32(a), _f32(b)
             with np.errstate(invalid="ignore"):
-                w.vcc = {"lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b, "eq": a == b, "ne": a != b, "lg": a != b,
-                         "neq": ~(a == b)}[cond].copy()
+                r = {"lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b, "eq": a == b, "ne": a != b, "lg": a != b,
+                     "neq": ~(a == b)}[cond].copy()
+            if ins.dst[0].kind == "vcc":
+                w.vcc = r
+            else:
+                self._wr64(w, ins.dst[0], sum(1 << i for i in range(64) if r[i]))
             return
+        if op == "v_cndmask_b32_e64":
+            a, b = self.rd_v(w, ins.src[0]), self.rd_v(w, ins.src[1])
+            bits = self._rd64(w, ins.src[2])
+            msk = np.array([(bits >> i) & 1 for i in range(64)], dtype=bool)
+            self.wr_v(w, ins.dst[0], np.where(msk, b, a)); return
         if op == "v_cndmask_b32":
             a, b = self.rd_v(w, ins.src[0]), self.rd_v(w, ins.src[1])
             self.wr_v(w, ins.dst[0], np.where(w.vcc, b, a)); return
