@@ -180,7 +180,7 @@ class FwdGen:
         SS[par]; sets s_flag (lane mask: some row's reference moved)"""
         t = self.tmp
         for rb in range(2):
-            if cls:
+            if cls and "mask" not in self.ablate:
                 p.v_lshrrev(t[1], 5, self.lane)
                 p.v_lshlrev(t[1], 2, t[1])
                 p.v_add_u32(t[1], k0, t[1])
