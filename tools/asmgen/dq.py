@@ -202,6 +202,40 @@ class DqGen:
         p.v_lshl_add_u32(t0, t1, 4, t0)
         p.v_and(t1, 1, lane)
         p.v_lshl_add_u32(self.l_tr0, t1, 3, t0)
+        # ---- K / V streams: descriptors and lane parts of the source offsets.  piece of row group 2 wave + e: rows
+        #      16 wave + 8 e + rr, chunk 4 cbl + (slot ^ ((2 e + (rr >> 2)) & 3))   (+ 8 chunks for the second half)
+        for d, nm in ((self.d_k, "k"), (self.d_v, "v")):
+            p.s_mov(d[0], P(nm + "_lo"))
+            p.s_mov(d[1], P(nm + "_hi"))
+            p.s_mov(d[2], P(nm + "_rng"))
+            p.s_mov(d[3], 0x00020000)
+        rr, slot = t0, t1
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.s_lshl_b32(st[0], wv, 4)
+        for e in range(2):
+            p.v_lshrrev(t3, 2, rr)
+            p.v_add_u32(t3, 2 * e, t3)
+            p.v_and(t3, 3, t3)
+            p.v_xor(t3, t3, slot)
+            p.v_lshl_add_u32(t3, t2, 2, t3)                   # + 4 cbl   (t2 = lane >> 5)
+            p.v_lshlrev(t3, 4, t3)                            # bytes inside the row
+            p.s_add_u32(st[1], st[0], 8 * e)
+            p.v_add_u32(self.vt[0], st[1], rr)                # row inside the tile
+            for col, nm in ((0, "k"), (1, "v")):
+                p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
+                p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+                if self.l_dma1 is not None:      # chunk 8 + (t3 >> 4) of the row must be < NCH
+                    p.v_lshrrev(self.vt[1], 4, t3)
+                    p.v_add_u32(self.l_dma1[e][col], 128, self.l_dma[e][col])
+                    p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
+                    p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
+        p.s_lshl_b32(self.s_wofs, wv, 12)                     # 4096 wave: the wave's four pieces inside an image
+        # requests in the order their data is needed: tile 0, the Q / dO fragments and row constants, tiles 1 and 2; the
+        # accumulators and constants are set up while they are in flight
+        p.s_mov(self.s_std, 0)
+        p.s_mov(st[3], 0)
+        self.emit_dma_tile(p, st[3])
         # row of the lane in block rb: qw0 + 32 rb + r ; qw0 = q0 + 64 rgi
         p.s_lshl_b32(st[0], self.s_rgi, 6)
         p.s_add_u32(st[0], st[0], P("q0"))                    # qw0
@@ -240,52 +274,22 @@ class DqGen:
             p.s_mov(self.d_x[3], 0x00020000)
             p.buffer_load(dst[0], t1, self.d_x, 0)
             p.buffer_load(dst[1], t3, self.d_x, 0)
-        for rb in range(2):
-            p.v_mul_f32(self.lse2[rb], P("nlog2e"), self.lse2[rb])
+        for j in (1, 2):
+            p.s_mov(self.s_std, j * STG_BYTES)
+            p.s_mov(st[3], j)
+            self.emit_dma_tile(p, st[3])
         # ---- mask constants
         p.v_mov(self.v_w, P("W"))
         p.v_mov(self.v_2e31, imm(0x80000000))
-        # ---- K / V streams: descriptors and lane parts of the source offsets.  piece of row group 2 wave + e: rows
-        #      16 wave + 8 e + rr, chunk 4 cbl + (slot ^ ((2 e + (rr >> 2)) & 3))   (+ 8 chunks for the second half)
-        for d, nm in ((self.d_k, "k"), (self.d_v, "v")):
-            p.s_mov(d[0], P(nm + "_lo"))
-            p.s_mov(d[1], P(nm + "_hi"))
-            p.s_mov(d[2], P(nm + "_rng"))
-            p.s_mov(d[3], 0x00020000)
-        rr, slot = t0, t1
-        p.v_bfe_u32(rr, lane, 2, 3)
-        p.v_and(slot, 3, lane)
-        p.s_lshl_b32(st[0], wv, 4)
-        for e in range(2):
-            p.v_lshrrev(t3, 2, rr)
-            p.v_add_u32(t3, 2 * e, t3)
-            p.v_and(t3, 3, t3)
-            p.v_xor(t3, t3, slot)
-            p.v_lshl_add_u32(t3, t2, 2, t3)                   # + 4 cbl   (t2 = lane >> 5)
-            p.v_lshlrev(t3, 4, t3)                            # bytes inside the row
-            p.s_add_u32(st[1], st[0], 8 * e)
-            p.v_add_u32(self.vt[0], st[1], rr)                # row inside the tile
-            for col, nm in ((0, "k"), (1, "v")):
-                p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
-                p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
-                if self.l_dma1 is not None:      # chunk 8 + (t3 >> 4) of the row must be < NCH
-                    p.v_lshrrev(self.vt[1], 4, t3)
-                    p.v_add_u32(self.l_dma1[e][col], 128, self.l_dma[e][col])
-                    p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
-                    p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
-        p.s_lshl_b32(self.s_wofs, wv, 12)                     # 4096 wave: the wave's four pieces inside an image
         # ---- accumulators
         for rb in range(2):
             for db in range(self.DB):
                 for i in range(16):
                     p.v_accvgpr_write(self.DQ[rb][db][i], 0)
-        # ---- first three tiles into stages 0, 1, 2
-        for j in range(3):
-            p.s_mov(self.s_std, j * STG_BYTES)
-            p.s_mov(st[3], j)
-            self.emit_dma_tile(p, st[3])
         p.s_waitcnt(vmcnt=2 * 4 * self.HALVES, note="Q / dO fragments, row constants, tile 0 landed (tiles 1, 2 in flight)")
         p.s_barrier()
+        for rb in range(2):
+            p.v_mul_f32(self.lse2[rb], P("nlog2e"), self.lse2[rb])
         p.v_mov(self.a_kn_e, self.l_row_e)
         p.v_xor(self.a_kn_o, 32, self.a_kn_e)
         self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)

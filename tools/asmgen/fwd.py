@@ -42,7 +42,7 @@ PARAMS = [
 
 
 class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128, ablate=(), lsum="mfma"):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128, ablate=(), lsum="mfma", stamps=False):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
@@ -94,10 +94,20 @@ class FwdGen:
         self.s_koff, self.s_voff = sa("s_koff"), sa("s_voff")
         self.s_wofs, self.s_cls = sa("s_wofs"), sa("s_cls")
         self.s_tmp = [sa("s_tmp%d" % i) for i in range(5)]
+        self.stamps = stamps              # diagnostic build (tools/stamps_fwd.py): s_memtime at the ends of prologue / loop / epilogue
+        if stamps:
+            self.s_tt = sa("s_tt", 2, 2)
+            self.s_T = [sa("s_T%d" % i) for i in range(5)]
         self.pool_next = 0
 
     def params(self):
-        return list(PARAMS)
+        return list(PARAMS) + (["dbg_lo", "dbg_hi", "bid", "t_entry"] if self.stamps else [])
+
+    def emit_stamp(self, p: Prog, k: int):
+        if self.stamps:
+            p.add(Instr("s_memtime", [self.s_tt], [], kind="fence"))
+            p.s_waitcnt(lgkmcnt=0)
+            p.s_mov(self.s_T[k], self.s_tt[0])
 
     def pool(self):
         r = self.POOL[self.pool_next % len(self.POOL)]
@@ -288,6 +298,7 @@ class FwdGen:
         t0, t1, t2, t3 = self.tmp[:4]
         st = self.s_tmp
         lane, wv = self.lane, self.s_wave
+        self.emit_stamp(p, 0)
         p.v_and(lane, 63, PV("tid"))
         p.v_lshrrev(t0, 6, PV("tid"))
         p.v_readfirstlane(wv, t0)
@@ -336,36 +347,6 @@ class FwdGen:
         p.v_lshl_add_u32(self.vo[0], t2, 4, t1)
         p.s_lshl_b32(st[1], P("q_sn"), 5)
         p.v_add_u32(self.vo[1], st[1], self.vo[0])
-        for rb in range(2):
-            for ks in range(self.DK):
-                p.buffer_load(self.QF[rb][ks], self.vo[rb], self.d_x, 0, offset=32 * ks)
-        # ---- softmax state: m = m0 of the wave's head, l = l0, O = 0 ; constants
-        p.s_cmp("eq_u32", self.s_hh, 1)
-        p.s_cselect(st[1], P("m0_1"), P("m0_0"))
-        p.s_cmp("eq_u32", self.s_hh, 2)
-        p.s_cselect(st[1], P("m0_2"), st[1])
-        p.s_cmp("eq_u32", self.s_hh, 3)
-        p.s_cselect(st[1], P("m0_3"), st[1])
-        if self.lsum_valu:
-            p.v_mov(t1, P("l0"))
-            p.v_cmp("gt_u32", 32, lane)
-        for rb in range(2):
-            p.v_mov(self.m[rb], st[1])
-            if self.lsum_valu:
-                p.v_cndmask(self.lsum[rb], 0, t1)                 # l0 once per row: lanes 0..31
-            else:
-                for i in range(16):
-                    p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
-            for db in range(self.DB):
-                for i in range(16):
-                    p.v_accvgpr_write(self.OACC[rb][db][i], 0)
-        ones = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
-        p.v_mov(t1, imm(ones))
-        for i in range(4):
-            p.v_accvgpr_write(self.ONES[i], t1)
-        p.v_mov(self.v_w, P("W"))
-        p.v_mov(self.v_2e31, imm(0x80000000))
-        p.v_mov(self.v_ninf, imm(NEG_INF))
         # ---- K / V streams (as dq.py)
         for d, nm in ((self.d_k, "k"), (self.d_v, "v")):
             p.s_mov(d[0], P(nm + "_lo"))
@@ -394,10 +375,45 @@ class FwdGen:
                     p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
                     p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
         p.s_lshl_b32(self.s_wofs, wv, 12)
-        for j in range(3):
+        # requests in the order their data is needed: tile 0, the Q fragments, tiles 1 and 2; the softmax state and the
+        # constants are set up while they are in flight
+        p.s_mov(self.s_std, 0)
+        p.s_mov(st[3], 0)
+        self.emit_dma_tile(p, st[3])
+        for rb in range(2):
+            for ks in range(self.DK):
+                p.buffer_load(self.QF[rb][ks], self.vo[rb], self.d_x, 0, offset=32 * ks)
+        for j in (1, 2):
             p.s_mov(self.s_std, j * STG_BYTES)
             p.s_mov(st[3], j)
             self.emit_dma_tile(p, st[3])
+        # ---- softmax state: m = m0 of the wave's head, l = l0, O = 0 ; constants
+        p.s_cmp("eq_u32", self.s_hh, 1)
+        p.s_cselect(st[1], P("m0_1"), P("m0_0"))
+        p.s_cmp("eq_u32", self.s_hh, 2)
+        p.s_cselect(st[1], P("m0_2"), st[1])
+        p.s_cmp("eq_u32", self.s_hh, 3)
+        p.s_cselect(st[1], P("m0_3"), st[1])
+        if self.lsum_valu:
+            p.v_mov(t1, P("l0"))
+            p.v_cmp("gt_u32", 32, lane)
+        for rb in range(2):
+            p.v_mov(self.m[rb], st[1])
+            if self.lsum_valu:
+                p.v_cndmask(self.lsum[rb], 0, t1)                 # l0 once per row: lanes 0..31
+            else:
+                for i in range(16):
+                    p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
+            for db in range(self.DB):
+                for i in range(16):
+                    p.v_accvgpr_write(self.OACC[rb][db][i], 0)
+        ones = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
+        p.v_mov(t1, imm(ones))
+        for i in range(4):
+            p.v_accvgpr_write(self.ONES[i], t1)
+        p.v_mov(self.v_w, P("W"))
+        p.v_mov(self.v_2e31, imm(0x80000000))
+        p.v_mov(self.v_ninf, imm(NEG_INF))
         p.s_waitcnt(vmcnt=2 * 4 * self.HALVES, note="Q fragments, tile 0 landed (tiles 1, 2 in flight)")
         p.s_barrier()
         # ---- pipeline fill: S^T of tile 0 and its softmax bookkeeping (general mask path: any tile class)
@@ -414,6 +430,7 @@ class FwdGen:
         p.s_mov(self.s_st, 0)
         p.s_mov(self.s_stn, STG_BYTES)
         p.s_mov(self.s_std, 3 * STG_BYTES)
+        self.emit_stamp(p, 1)
         return p
 
     # ------------------------------------------------------------------ loop head
@@ -492,6 +509,7 @@ class FwdGen:
         t0, t1, t2, t3, t4, t5 = self.tmp
         st = self.s_tmp
         p.label("L_done%=")
+        self.emit_stamp(p, 2)
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
         # O[row, d] = O^T[d, row] / l (l = 0 -> 1), LSE = ln2 (m + log2 l)
         p.s_mul_i32(st[1], self.s_hh, P("o_hs"))
@@ -561,7 +579,26 @@ class FwdGen:
         p.v_add_u32(t5, 128, t1)
         p.buffer_store(lg[0], t1, self.d_x, 0)
         p.buffer_store(lg[1], t5, self.d_x, 0)
+        self.emit_stamp(p, 3)
         p.s_waitcnt(vmcnt=0)
+        if self.stamps:
+            # lane 0 of every wave: [t_entry, asm start, loop start, loop end, stores issued, stores done, tiles, 0] at
+            # dbg[(4 bid + wave) * 32 bytes] (other lanes out of range)
+            self.emit_stamp(p, 4)
+            p.s_mov(self.d_x[0], P("dbg_lo"))
+            p.s_mov(self.d_x[1], P("dbg_hi"))
+            p.s_mov(self.d_x[3], 0x00020000)
+            p.s_lshl_b32(st[0], P("bid"), 2)
+            p.s_add_u32(st[0], st[0], self.s_wave)
+            p.s_lshl_b32(st[0], st[0], 5)
+            p.s_add_u32(self.d_x[2], st[0], 32, note="records end behind this wave's 32 bytes")
+            p.v_mov(t0, st[0])
+            p.v_cmp("eq_u32", 0, self.lane)
+            p.v_cndmask(t0, self.v_oob, t0)
+            for k, src in enumerate([P("t_entry")] + self.s_T + [P("nt")]):
+                p.v_mov(t1, src)
+                p.buffer_store(t1, t0, self.d_x, 0, offset=4 * k)
+            p.s_waitcnt(vmcnt=0)
         return p
 
     def build(self):
