@@ -42,7 +42,7 @@ PARAMS = [
 
 
 class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128, ablate=(), lsum="mfma", stamps=False):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128, ablate=(), lsum="mfma", stamps=False, kpre=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
@@ -52,6 +52,9 @@ class FwdGen:
         # LDS-DMA deadlines inside a trip (early and staggered; placing them in the PV half measured 0.8 % slower)
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
+        # the first four K row fragments of the NEXT iteration's S^T chains are read at the end of the current one (their
+        # latency passes under the loop head instead of in front of the first MFMA); needs tile i+2 landed at barrier i
+        self.kpre = kpre
         self.lsum_valu = lsum == "valu"   # row sums: f32 adds beside the exponentials ("valu") or ones-MFMAs ("mfma")
         self.vfirst, self.sfirst = vfirst, sfirst
         va = self.va = Alloc("v", vfirst, 255)
@@ -170,15 +173,24 @@ class FwdGen:
         p.s_cselect(self.s_cls, 0, t[1])
 
     # ------------------------------------------------------------------ phases
-    def emit_A(self, p: Prog, par_next: int, e, o):
-        """S^T of a tile whose K image row-read addresses are e / o: four chains of 8, into SS[par_next]"""
+    def emit_k_prefetch(self, p: Prog, e, o, deadline=None):
+        """first four K row fragments (key half 0, k-steps 0..3) of a tile, into pool slots 0..3"""
+        for ks in range(4):      # (DK >= 4 for every supported head dim)
+            ins = p.ds_read_b128(self.POOL[ks], o if ks & 1 else e, 512 * (ks >> 1), mem=("stage_r",), note="K rows, next trip")
+            if deadline is not None:
+                ins.mods["alap"] = deadline + 6 * ks
+
+    def emit_A(self, p: Prog, par_next: int, e, o, pre=False):
+        """S^T of a tile whose K image row-read addresses are e / o: four chains of 8, into SS[par_next]; pre: pool slots
+        0..3 already hold the first four fragments"""
         dt = self.dtype
         for kh in range(2):
             kf = []
             for ks in range(self.DK):
                 f = self.pool()
                 base = o if ks & 1 else e
-                p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
+                if not (pre and kh == 0 and ks < 4):
+                    p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
                 kf.append(f)
             for rb in range(2):
                 acc = self.SS[par_next][kh][rb]
@@ -430,6 +442,12 @@ class FwdGen:
         p.s_mov(self.s_st, 0)
         p.s_mov(self.s_stn, STG_BYTES)
         p.s_mov(self.s_std, 3 * STG_BYTES)
+        if self.kpre:
+            p.s_waitcnt(vmcnt=0, note="tiles 1, 2 landed (own pieces)")
+            p.s_barrier()
+            p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
+            p.v_xor(self.a_k_o, 32, self.a_k_e)
+            self.emit_k_prefetch(p, self.a_k_e, self.a_k_o)
         self.emit_stamp(p, 1)
         return p
 
@@ -443,8 +461,13 @@ class FwdGen:
         p.s_cmp_lg_u64(self.s_flag, 0)
         p.s_cbranch("scc1", "L_rescale%=")
         p.label("L_top_a%=")
-        p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
-        p.s_barrier()
+        if self.kpre:
+            p.s_waitcnt(vmcnt=0, note="tile it+2 landed (own pieces; issued a whole iteration ago)")
+            p.s_barrier()
+            p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last iteration")
+        else:
+            p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
+            p.s_barrier()
         for code in (0, 4, 1, 5, 3, 7, 2):
             p.s_cmp("eq_u32", self.s_cls, code)
             p.s_cbranch("scc1", "L_body%d%%=" % code)
@@ -478,14 +501,15 @@ class FwdGen:
         p = Prog()
         self.pool_next = 0
         st = self.s_tmp
-        p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
-        p.v_xor(self.a_k_o, 32, self.a_k_e)
+        if not self.kpre:        # (with the prefetch the previous iteration left the addresses of tile i+1's K image)
+            p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
+            p.v_xor(self.a_k_o, 32, self.a_k_e)
         p.v_add_u32(self.a_tr0, self.s_st, self.l_tr0)
         p.v_xor(self.a_tr1, 32, self.a_tr0)
         p.s_add_u32(st[4], self.s_it, 3)
         self.emit_dma_tile(p, st[4], spread=True)
         if cls_next != 3:
-            self.emit_A(p, par ^ 1, self.a_k_e, self.a_k_o)
+            self.emit_A(p, par ^ 1, self.a_k_e, self.a_k_o, pre=self.kpre)
         self.emit_E(p, par)
         self.emit_C(p, par)
         if cls_next != 3:
@@ -500,6 +524,16 @@ class FwdGen:
         p.s_add_u32(t0, self.s_std, STG_BYTES)
         p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
         self.emit_next_class(p, self.s_it)
+        if self.kpre:            # K image of tile i+2 (landed before this iteration's barrier): addresses + first fragments
+            p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
+            p.v_xor(self.a_k_o, 32, self.a_k_e)
+            self.emit_k_prefetch(p, self.a_k_e, self.a_k_o, deadline=(8 * self.DK + 8 * self.DB + 8) * 32 - 300)
+        if self.ablate:          # knock-out builds for tools/ab.py (wrong results): what does an iteration cost without ...
+            kill = lambda it: (("dma" in self.ablate and it.kind == "dma") or ("exp" in self.ablate and it.kind == "trans") or
+                               ("ldsr" in self.ablate and it.kind == "ds_read") or
+                               ("mfma_pv" in self.ablate and it.kind == "mfma" and it.tag in ("PV", "l")) or
+                               ("mfma_s" in self.ablate and it.kind == "mfma" and it.tag == "S"))
+            p.items = [it for it in p.items if not kill(it)]
         return p
 
     # ------------------------------------------------------------------ epilogue
@@ -615,7 +649,8 @@ class FwdGen:
                 b = fix_hazards(b, loop=True)
                 # every load into a register is consumed inside the body: nothing outstanding at its end
                 items += b
-                items.append(Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 0}))
+                if not self.kpre:
+                    items.append(Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 0}))
                 items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
         items += finish_block(self.rescale().items)
         items += finish_block(self.epilogue().items)
