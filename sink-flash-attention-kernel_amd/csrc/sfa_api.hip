@@ -207,7 +207,7 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
 }
 
 int sfa_varlen_supported(int dtype, int64_t D) {
-    return fwd_mfma_supported(dtype, (int)D) && bwd_mfma_supported(dtype, (int)D) ? 1 : 0;
+    return fwd_mfma_supported(dtype, (int)D) && bwd_mfma_varlen_supported(dtype, (int)D) ? 1 : 0;
 }
 
 // shared checks of the packed entry points; on success *p describes the packed tensors (B = 1, N = total rows) and

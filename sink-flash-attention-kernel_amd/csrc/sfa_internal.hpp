@@ -25,6 +25,7 @@ int fwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
 
 // sfa_bwd_mfma.hip
 bool bwd_mfma_supported(int dtype, int D);
+bool bwd_mfma_varlen_supported(int dtype, int D);   // packed (cu_seqlens) launches
 size_t bwd_mfma_workspace_bytes(const Problem& p, int dtype, unsigned flags);
 int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const sfa_tensor* d_o,
              const float* lse, const float* delta, const sfa_tensor* dq, const sfa_tensor* dk,

@@ -397,9 +397,8 @@ def test_hand_placed_kernels_other_head_dims(D, dtype):
 @pytest.mark.parametrize("D,dtype,W", [(256, torch.bfloat16, 300), (256, torch.float16, 0), (32, torch.bfloat16, 200),
                                        (32, torch.float16, 50)])
 def test_mfma_kernels_head_dims_32_and_256(D, dtype, W):
-    """head dims the reference lists beside 64 / 128 (README "Head dims: 64, 128, 256") and a small one: the forward
-    runs the MFMA kernel for both, the backward for 32 (the 256-wide dK / dV accumulators do not fit the MFMA backward:
-    exact-f32 kernels there); GQA, sinks, s_aux, ragged N, against the oracle"""
+    """head dims the reference lists beside 64 / 128 (README "Head dims: 64, 128, 256") and a small one: forward and
+    backward run MFMA kernels for both (256: split-column dK/dV kernel); GQA, sinks, s_aux, ragged N, against the oracle"""
     B, Hq, Hkv, N, ns = 2, 4, 2, 333, 4
     W = W or N
     g = torch.Generator().manual_seed(D + 1)
@@ -411,7 +410,7 @@ def test_mfma_kernels_head_dims_32_and_256(D, dtype, W):
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     assert "fwd_mfma" in _path() and "d%d" % D in _path(), _path()
     out.backward(do.to(DEV))
-    assert ("bwd_mfma" in _path()) == (D == 32), _path()
+    assert "bwd_mfma" in _path() and "d%d" % D in _path(), _path()
     o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
     dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
     to = 2e-2 if dtype == torch.bfloat16 else 1e-2
@@ -420,6 +419,26 @@ def test_mfma_kernels_head_dims_32_and_256(D, dtype, W):
     assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
     assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
+
+
+def test_head_dim_256_backward_larger_shapes():
+    """head dim 256 backward on shapes with several key blocks, a window shorter than the sequence, MHA and GQA, and
+    N_q < N_kv (queries are the last rows), against the banded oracle"""
+    for (B, Hq, Hkv, N, Nk, ns, W) in ((1, 4, 4, 700, 700, 4, 200), (2, 4, 1, 515, 515, 0, 515), (1, 2, 1, 200, 456, 3, 128)):
+        g = torch.Generator().manual_seed(N)
+        dt = torch.bfloat16
+        q, do = rand((B, Hq, N, 256), g, dt), rand((B, Hq, N, 256), g, dt)
+        k, v = rand((B, Hkv, Nk, 256), g, dt), rand((B, Hkv, Nk, 256), g, dt)
+        qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        out = _op()(qd, kd, vd, num_sink=ns, window_size=W)
+        out.backward(do.to(DEV))
+        assert "bwd_mfma" in _path() and "d256" in _path(), _path()
+        o_r, _ = oracle_fwd(q, k, v, ns, W)
+        dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
+        assert_close(out, o_r, 2e-2, 2e-2, "fwd")
+        assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
+        assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
+        assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
 
 
 def test_baseline_c4_full_shape():
