@@ -277,7 +277,8 @@ int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v
     record_stage(0, s);
     const bool fuse = bwd_mfma_wants_consts() && bwd_preprocess_vectorised(o, d_o, p);
     st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s,           // row-wise: no sequence structure
-                        fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr, bwd_mfma_lse_factor(p));
+                        fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr,
+                        bwd_mfma_lse_factor(run));   // (the LAUNCH problem: the kernel choice clamps the window to max_seqlen)
     record_stage(1, s);
     if (st) return st;
     st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, run, 0, s, fuse);

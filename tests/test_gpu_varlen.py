@@ -49,7 +49,9 @@ def test_varlen_fwd_bwd_matches_per_sequence_oracle(dtype):
     (8, 2, 128, 4, 300, [0, 1000, 1001, 1900, 4000, 4127]),      # long + 1-row + ragged sequences, GQA
     (4, 4, 64, 0, 64, [0, 63, 64, 200, 200, 455]),               # MHA, D=64, an EMPTY sequence in the pack
     (8, 1, 80, 130, 50, [0, 129, 700]),                          # MQA, D=80, sinks longer than a key block
-    (4, 2, 96, 2, 100000, [0, 257, 640])])                       # window larger than every sequence
+    (4, 2, 96, 2, 100000, [0, 257, 640]),                        # window larger than every sequence
+    (4, 1, 96, 0, 4096, [0, 200, 264, 265]),                     # pack longer than 256 rows, every sequence shorter: the
+    (1, 1, 80, 130, 300, [0, 200, 400])])                        # row constants must follow the LAUNCH's kernel choice
 def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu):
     """The packed kernels (cu_seqlens inside the grid) against the per-sequence oracle, forward and backward, and
     against the sequence-by-sequence path of the same library."""

@@ -28,7 +28,7 @@ def run(q, k, v, do, ns, W, sa, generic):
 
 
 for case in range(n_cases):
-    D = rng.choice([64, 80, 96, 128])
+    D = rng.choice([32, 64, 80, 96, 128, 128, 256])
     Hkv = rng.choice([1, 2, 4])
     g = rng.choice([1, 2, 4, 8])
     Hq = Hkv * g
