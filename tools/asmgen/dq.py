@@ -43,10 +43,11 @@ PARAMS = [
 
 
 class DqGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, D=128, ablate=()):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
+        self.dma_t0, self.dma_dt = dma_t0, dma_dt   # deadlines of the eight LDS-DMA pieces inside a trip (cycles of the model)
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
         # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
         self.D, self.DK, self.DB, self.NCH = D, D // 16, (D + 31) // 32, D // 8
@@ -136,7 +137,7 @@ class DqGen:
                         p.s_add_m0(t[1], img + 2048 * e + 1024 * half)
                     ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage",))
                     if spread:
-                        ins.mods["alap"] = 40 + 120 * k
+                        ins.mods["alap"] = self.dma_t0 + self.dma_dt * k
                     k += 1
 
     def emit_k_prefetch(self, p: Prog, e, o, deadline=None):

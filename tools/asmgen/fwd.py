@@ -42,7 +42,7 @@ PARAMS = [
 
 
 class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, thr=8.0, dma_t0=40, dma_dt=120, D=128, ablate=(), lsum="mfma", stamps=False, kpre=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", stamps=False, kpre=True, kpre_dl=300):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
@@ -54,7 +54,7 @@ class FwdGen:
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         # the first four K row fragments of the NEXT iteration's S^T chains are read at the end of the current one (their
         # latency passes under the loop head instead of in front of the first MFMA); needs tile i+2 landed at barrier i
-        self.kpre = kpre
+        self.kpre, self.kpre_dl = kpre, kpre_dl
         self.lsum_valu = lsum == "valu"   # row sums: f32 adds beside the exponentials ("valu") or ones-MFMAs ("mfma")
         self.vfirst, self.sfirst = vfirst, sfirst
         va = self.va = Alloc("v", vfirst, 255)
@@ -527,7 +527,7 @@ class FwdGen:
         if self.kpre:            # K image of tile i+2 (landed before this iteration's barrier): addresses + first fragments
             p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
             p.v_xor(self.a_k_o, 32, self.a_k_e)
-            self.emit_k_prefetch(p, self.a_k_e, self.a_k_o, deadline=(8 * self.DK + 8 * self.DB + 8) * 32 - 300)
+            self.emit_k_prefetch(p, self.a_k_e, self.a_k_o, deadline=(8 * self.DK + 8 * self.DB + 8) * 32 - self.kpre_dl)
         if self.ablate:          # knock-out builds for tools/ab.py (wrong results): what does an iteration cost without ...
             kill = lambda it: (("dma" in self.ablate and it.kind == "dma") or ("exp" in self.ablate and it.kind == "trans") or
                                ("ldsr" in self.ablate and it.kind == "ds_read") or
