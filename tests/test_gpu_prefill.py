@@ -441,6 +441,35 @@ def test_head_dim_256_backward_larger_shapes():
         assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
 
 
+@pytest.mark.parametrize("B,Hq,Hkv,N,Nk,D,ns,W,dtype", [
+    (1, 4, 1, 2100, 2100, 128, 4, 128, torch.bfloat16),     # 7 chunks of block 0's sweep, GQA, ragged last chunk
+    (2, 2, 2, 1500, 1500, 64, 70, 300, torch.float16),      # MHA, head dim 64, sinks beyond one 64-key wave
+    (1, 2, 1, 1000, 1300, 128, 4, 64, torch.bfloat16),      # N_q < N_kv
+    (1, 2, 1, 3000, 3000, 96, 300, 512, torch.bfloat16),    # more sink keys than a key block holds
+])
+def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype):
+    """key block 0 (the sink keys see every row) is swept by several workgroups whose partial dK / dV are added up:
+    against the oracle, and bitwise deterministic across runs"""
+    from sink_attention import _native
+    g = torch.Generator().manual_seed(N + D)
+    q, do = rand((B, Hq, N, D), g, dtype), rand((B, Hq, N, D), g, dtype)
+    k, v = rand((B, Hkv, Nk, D), g, dtype), rand((B, Hkv, Nk, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    grads = []
+    for _ in range(2):
+        qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        sad = sa.to(DEV).requires_grad_(True)
+        out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
+        out.backward(do.to(DEV))
+        assert "dkdvasm4x64" in _path(), _path()
+        grads.append((qd.grad.clone(), kd.grad.clone(), vd.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W, sa)
+    assert_close(grads[0][0], dq_r, 5e-2, 5e-2, "dq")
+    assert_close(grads[0][1], dk_r, 1e-1, 5e-2, "dk")
+    assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
+
+
 def test_baseline_c4_full_shape():
     """BASELINE.json configs[3] at its REAL shape: gpt-oss-20b sliding layer, bf16, H_q=64, H_kv=8, D=80, N=8192,
     window=128, s_aux, fwd+bwd including ds_aux, against the banded oracle (cheap at W=128)."""

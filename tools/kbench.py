@@ -24,6 +24,9 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "D256": (4, 16, 4, 8192, 256, 4, 4096, False),
     "C2gqa": (4, 32, 8, 4096, 128, 4, 1024, False),
     "W128d128": (4, 32, 8, 8192, 128, 4, 128, False),
+    "refB1N32k": (1, 32, 8, 32768, 128, 4, 4096, False),
+    "refB1N8k": (1, 32, 8, 8192, 128, 4, 4096, False),
+    "slmB1": (1, 32, 8, 16384, 128, 4, 1024, False),
     "D32": (4, 32, 8, 8192, 32, 4, 4096, False),
 }
 
