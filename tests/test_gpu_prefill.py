@@ -472,6 +472,31 @@ def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype):
     assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
 
 
+def test_small_grids_take_the_compiled_dkdv_kernel():
+    """a grid of 256-key blocks smaller than the chip goes to the compiled dK/dV kernel (128-key blocks: twice the
+    workgroups); same numbers within tolerance either way"""
+    from sink_attention import _native
+    lib = _native.lib()
+    B, Hq, Hkv, N, D, ns, W = 1, 8, 2, 1024, 128, 4, 4096
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.bfloat16, seed=5)
+    do = rand((B, Hq, N, D), g, torch.bfloat16)
+    res = {}
+    try:
+        for force in (0, 1):
+            lib.sfa_debug_set_variant(4, force)
+            qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+            _op()(qd, kd, vd, num_sink=ns, window_size=W).backward(do.to(DEV))
+            assert ("dkdvasm4x64" if force else "dkdvws8") in _path(), _path()
+            res[force] = (qd.grad, kd.grad, vd.grad)
+    finally:
+        lib.sfa_debug_set_variant(4, 1)
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
+    for force in (0, 1):
+        assert_close(res[force][0], dq_r, 5e-2, 5e-2, "dq")
+        assert_close(res[force][1], dk_r, 1e-1, 5e-2, "dk")
+        assert_close(res[force][2], dv_r, 1e-1, 5e-2, "dv")
+
+
 def test_baseline_c4_full_shape():
     """BASELINE.json configs[3] at its REAL shape: gpt-oss-20b sliding layer, bf16, H_q=64, H_kv=8, D=80, N=8192,
     window=128, s_aux, fwd+bwd including ds_aux, against the banded oracle (cheap at W=128)."""
