@@ -26,6 +26,8 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "W128d128": (4, 32, 8, 8192, 128, 4, 128, False),
     "refB1N32k": (1, 32, 8, 32768, 128, 4, 4096, False),
     "refB1N8k": (1, 32, 8, 8192, 128, 4, 4096, False),
+    "refB1N16k": (1, 32, 8, 16384, 128, 4, 4096, False),
+    "refB2N8k": (2, 32, 8, 8192, 128, 4, 4096, False),
     "refB1N512": (1, 32, 8, 512, 128, 4, 4096, False),
     "refB1N1k": (1, 32, 8, 1024, 128, 4, 4096, False),
     "refB1N2k": (1, 32, 8, 2048, 128, 4, 4096, False),
