@@ -33,7 +33,7 @@ for case in range(n_cases):
     g = rng.choice([1, 2, 4, 8])
     Hq = Hkv * g
     B = rng.choice([1, 2])
-    N = rng.choice([1, 7, 31, 33, 64, 65, 100, 127, 128, 129, 200, 257, 500, 777, 1024, 1500])
+    N = rng.choice([1, 7, 31, 33, 64, 65, 100, 127, 128, 129, 200, 257, 500, 777, 1024, 1500, 2500, 4100])
     ns = rng.choice([0, 1, 4, 63, 64, 65, 130])
     W = rng.choice([0, 1, 5, 31, 64, 100, 128, 300, 1000, 4096])
     dt = rng.choice([torch.bfloat16, torch.float16])
