@@ -16,6 +16,7 @@ void* g_debug_ptr = nullptr;
 int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sfa_debug_set_variant: A/B builds (-DSFA_AB) only
 static void* const* g_stage_events = nullptr;
 static int g_stage_count = 0;
+bool stage_events_armed() { return g_stage_events != nullptr; }
 void record_stage(int i, hipStream_t stream) {
     if (g_stage_events && i < g_stage_count && g_stage_events[i]) (void)hipEventRecord((hipEvent_t)g_stage_events[i], stream);
 }

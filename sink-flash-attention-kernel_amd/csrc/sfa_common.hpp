@@ -18,6 +18,7 @@ namespace sfa {
 void set_error(const char* fmt, ...);
 void set_path(const char* fmt, ...);
 void record_stage(int i, hipStream_t stream);  // no-op unless sfa_debug_set_stage_events() armed it
+bool stage_events_armed();
 extern void* g_debug_ptr;                       // sfa_debug_set_ptr(): device buffer of the stamped diagnostic bodies
 extern int g_variant[8];                        // sfa_debug_set_variant(): 0 = dK/dV body, 1 = forward, 2 = dQ (A/B builds)
 inline int variant(int which) { return __atomic_load_n(&g_variant[which], __ATOMIC_RELAXED); }
