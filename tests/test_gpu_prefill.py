@@ -448,6 +448,7 @@ def test_head_dim_256_backward_larger_shapes():
     (1, 2, 1, 3000, 3000, 96, 300, 512, torch.bfloat16),    # more sink keys than a key block holds
     (1, 4, 1, 2100, 2100, 64, 4, 100, torch.bfloat16),      # short window below head dim 128: the compiled kernel's split
     (2, 2, 1, 900, 1200, 80, 130, 64, torch.float16),       # the same with N_q < N_kv and sinks beyond a 128-key block
+    (1, 2, 1, 20000, 20000, 128, 4, 32, torch.bfloat16),    # more chunks than the cap of 64 (banded oracle)
 ])
 def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype):
     """key block 0 (the sink keys see every row) is swept by several workgroups whose partial dK / dV are added up:
