@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """GPU runs: keep the hand-placed dK/dV kernel on the small shapes of the parity tests (the library would hand grids
-    smaller than the chip to the compiled kernel; tests/test_gpu_prefill.py::test_small_grids_take_the_compiled_dkdv_kernel
+    smaller than the chip to the compiled kernel; tests/test_gpu_prefill.py::test_small_grids_row_split_or_compiled_dkdv_kernel
     switches the rule back on for itself)."""
     if any("gpu" in it.keywords for it in items):
         try:

@@ -473,29 +473,36 @@ def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype):
     assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
 
 
-def test_small_grids_take_the_compiled_dkdv_kernel():
-    """a grid of 256-key blocks smaller than the chip goes to the compiled dK/dV kernel (128-key blocks: twice the
-    workgroups); same numbers within tolerance either way"""
+def test_small_grids_row_split_or_compiled_dkdv_kernel():
+    """a grid of 256-key blocks smaller than the chip: a dense batch (N_q = N_kv) keeps the hand-placed dK/dV kernel and
+    cuts EVERY block's sweep into chunks (row split, partial dK / dV added up in a fixed order); with N_q < N_kv the
+    workspace query cannot size the partials and the compiled kernel (128-key blocks: twice the workgroups) takes over.
+    Both against the oracle, with the library's own rule (the other GPU tests force the hand-placed kernel)."""
     from sink_attention import _native
     lib = _native.lib()
-    B, Hq, Hkv, N, D, ns, W = 1, 8, 2, 1024, 128, 4, 4096
-    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.bfloat16, seed=5)
-    do = rand((B, Hq, N, D), g, torch.bfloat16)
-    res = {}
     try:
-        for force in (0, 1):
-            lib.sfa_debug_set_variant(4, force)
-            qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
-            _op()(qd, kd, vd, num_sink=ns, window_size=W).backward(do.to(DEV))
-            assert ("dkdvasm4x64" if force else "dkdvws8") in _path(), _path()
-            res[force] = (qd.grad, kd.grad, vd.grad)
+        lib.sfa_debug_set_variant(4, 0)
+        for (B, Hq, Hkv, N, Nk, D, ns, W, want) in ((1, 4, 1, 2048, 2048, 128, 4, 512, "dkdvasm4x64"),      # one KV head: 8 blocks
+                                                    (1, 4, 1, 1500, 1500, 64, 300, 700, "dkdvasm4x64"),     # sinks over two blocks
+                                                    (2, 4, 2, 1000, 1000, 128, 0, 1000, "dkdvasm4x64"),     # causal, no sinks
+                                                    (1, 8, 2, 1024, 1200, 128, 4, 4096, "dkdvws8")):        # N_q < N_kv
+            q, do = rand((B, Hq, N, D), torch.Generator().manual_seed(N), torch.bfloat16), None
+            g = torch.Generator().manual_seed(N + 1)
+            do = rand((B, Hq, N, D), g, torch.bfloat16)
+            k, v = rand((B, Hkv, Nk, D), g, torch.bfloat16), rand((B, Hkv, Nk, D), g, torch.bfloat16)
+            grads = []
+            for _ in range(2):
+                qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+                _op()(qd, kd, vd, num_sink=ns, window_size=W).backward(do.to(DEV))
+                assert want in _path(), _path()
+                grads.append((qd.grad.clone(), kd.grad.clone(), vd.grad.clone()))
+            assert all(torch.equal(a, b) for a, b in zip(*grads))          # deterministic
+            dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
+            assert_close(grads[0][0], dq_r, 5e-2, 5e-2, "dq")
+            assert_close(grads[0][1], dk_r, 1e-1, 5e-2, "dk")
+            assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
     finally:
         lib.sfa_debug_set_variant(4, 1)
-    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
-    for force in (0, 1):
-        assert_close(res[force][0], dq_r, 5e-2, 5e-2, "dq")
-        assert_close(res[force][1], dk_r, 1e-1, 5e-2, "dk")
-        assert_close(res[force][2], dv_r, 1e-1, 5e-2, "dv")
 
 
 def test_baseline_c4_full_shape():

@@ -27,6 +27,9 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "refB1N32k": (1, 32, 8, 32768, 128, 4, 4096, False),
     "refB1N8k": (1, 32, 8, 8192, 128, 4, 4096, False),
     "refB1N16k": (1, 32, 8, 16384, 128, 4, 4096, False),
+    "tp8N8k": (1, 4, 1, 8192, 128, 4, 4096, False),
+    "tp8N32k": (1, 4, 1, 32768, 128, 4, 4096, False),
+    "tp4N8k": (1, 8, 2, 8192, 128, 4, 4096, False),
     "refB2N8k": (2, 32, 8, 8192, 128, 4, 4096, False),
     "refB1N512": (1, 32, 8, 512, 128, 4, 4096, False),
     "refB1N1k": (1, 32, 8, 1024, 128, 4, 4096, False),
