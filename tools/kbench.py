@@ -30,6 +30,10 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "tp8N8k": (1, 4, 1, 8192, 128, 4, 4096, False),
     "tp8N32k": (1, 4, 1, 32768, 128, 4, 4096, False),
     "tp4N8k": (1, 8, 2, 8192, 128, 4, 4096, False),
+    "oss_tp8_swa": (1, 8, 1, 8192, 64, 0, 128, True),
+    "oss_tp8_full": (1, 8, 1, 8192, 64, 0, 8192, True),
+    "oss_swa": (1, 64, 8, 8192, 64, 0, 128, True),
+    "oss_full": (1, 64, 8, 8192, 64, 0, 8192, True),
     "refB2N8k": (2, 32, 8, 8192, 128, 4, 4096, False),
     "refB1N512": (1, 32, 8, 512, 128, 4, 4096, False),
     "refB1N1k": (1, 32, 8, 1024, 128, 4, 4096, False),
