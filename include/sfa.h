@@ -116,8 +116,10 @@ int sfa_fwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
  * Backward.  Inputs q,k,v,o,do,lse,s_aux as produced/consumed by sfa_fwd.
  *   dq [B,Hq,N,D]; dk,dv [B,Hkv,N,D] (already summed over the GQA group);
  *   ds_aux nullable [Hq] float32 (required non-null iff s_aux non-null).
- *   workspace: sfa_bwd_workspace_bytes() bytes of device scratch, 256-byte aligned.
- *   Deterministic: the same inputs give bitwise-identical outputs.
+ *   workspace: sfa_bwd_workspace_bytes() bytes of device scratch, 256-byte aligned (N = query rows; the size covers
+ *   Delta, the ds_aux partials, the row constants and, where the dK/dV sweep is split into chunks, their partial dK / dV:
+ *   the query is an upper bound for every N_kv >= N).  Needs no initialisation, holds no state between calls.
+ *   Deterministic: the same inputs give bitwise-identical outputs (partial sums are added in a fixed order).
  */
 size_t sfa_bwd_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t N, int64_t D, int dtype,
                                int num_sink, int window, unsigned flags);
