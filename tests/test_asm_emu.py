@@ -22,10 +22,12 @@ from oracle import sink_oracle as O                   # noqa: E402
 _PROGS = {}
 
 
-def _prog(dtype, sched, gen=DkdvGen, D=128):
-    key = (dtype, sched, gen, D)
+def _prog(dtype, sched, gen=DkdvGen, D=128, persist=True):
+    """persist (forward, dQ): the work-list form of the body (what ships) or the one-item-per-workgroup form"""
+    key = (dtype, sched, gen, D, persist)
     if key not in _PROGS:
-        _PROGS[key] = gen(dtype, sched=sched, D=D).build()
+        kw = {} if gen is DkdvGen else {"persist": persist}
+        _PROGS[key] = gen(dtype, sched=sched, D=D, **kw).build()
     return _PROGS[key]
 
 
@@ -89,24 +91,31 @@ def test_stamped_diagnostic_body_runs_and_agrees():
     (1, 4, 1, 520, 650, 0, 256, "f16"),       # the same with N_q < N_kv and no sinks
 ])
 def test_dq_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype):
+    """the work-list (persistent) body: two workgroups share the items, so every item transition (K / V ring running on
+    into the next item, requests before the stores) and the last-item exit are executed, under the emulator's wait and
+    LDS-DMA race checks"""
     q, k, v, do, lse, delta, _, _ = _case(B, Hq, Hkv, N, Nk, ns, W, dtype, seed=N + 1)
     ref = _case.dq
-    got = run_dq(_prog(dtype, True, DqGen), q, k, v, do, lse, delta, ns, W, dtype)
+    got = run_dq(_prog(dtype, True, DqGen), q, k, v, do, lse, delta, ns, W, dtype, persist=True, n_wg=2)
     err = (got.double() - ref).abs()
     assert (err <= 5e-2 + 5e-2 * ref.abs()).all() and err.max().item() < 3e-2, err.max().item()
 
 
-def test_dq_scheduled_body_equals_program_order_bitwise():
+@pytest.mark.parametrize("n_wg", [1, 3])
+def test_dq_work_list_body_equals_one_item_body_bitwise(n_wg):
+    """every item of a work list computes what the one-item-per-workgroup body computes (the A/B partner kept in the
+    library), whatever the number of workgroups the list is cut for; scheduled = program order for both"""
     q, k, v, do, lse, delta, _, _ = _case(1, 4, 1, 200, 200, 4, 70, "bf16", seed=6)
-    a = run_dq(_prog("bf16", False, DqGen), q, k, v, do, lse, delta, 4, 70, "bf16")
-    b = run_dq(_prog("bf16", True, DqGen), q, k, v, do, lse, delta, 4, 70, "bf16")
-    assert torch.equal(a, b)
+    a = run_dq(_prog("bf16", False, DqGen, persist=False), q, k, v, do, lse, delta, 4, 70, "bf16")
+    b = run_dq(_prog("bf16", True, DqGen, persist=False), q, k, v, do, lse, delta, 4, 70, "bf16")
+    c = run_dq(_prog("bf16", True, DqGen), q, k, v, do, lse, delta, 4, 70, "bf16", persist=True, n_wg=n_wg)
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm assembler not installed")
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_dq_body_assembles_for_gfx950(dtype):
-    ok, err = assemble(_prog(dtype, True, DqGen))
+@pytest.mark.parametrize("dtype,persist", [("bf16", True), ("f16", True), ("bf16", False)])
+def test_dq_body_assembles_for_gfx950(dtype, persist):
+    ok, err = assemble(_prog(dtype, True, DqGen, persist=persist))
     assert ok, err[:4000]
 
 
@@ -128,27 +137,30 @@ def test_fwd_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype, au
         k[:, :, Nk - 40] = q[:, 0, N - 1] * 3
     sa = torch.randn(Hq, generator=g) * 0.5 if aux else None
     o_ref, lse_ref = O.sink_attention_dense(q, k, v, ns, W, sa)
-    o, lse = run_fwd(_prog(dtype, True, FwdGen), q, k, v, ns, W, sa, dtype)
+    o, lse = run_fwd(_prog(dtype, True, FwdGen), q, k, v, ns, W, sa, dtype, persist=True, n_wg=2)      # the work-list body
     assert (o.double() - o_ref).abs().max().item() < (1e-2 if dtype == "bf16" else 2e-3)
     fin = torch.isfinite(lse_ref)
     assert (lse.double()[fin] - lse_ref[fin]).abs().max().item() < 5e-3
     assert (lse[~fin] == float("-inf")).all()
 
 
-def test_fwd_scheduled_body_equals_program_order_bitwise():
+@pytest.mark.parametrize("n_wg", [1, 3])
+def test_fwd_work_list_body_equals_one_item_body_bitwise(n_wg):
     g = torch.Generator().manual_seed(8)
     q = torch.randn(1, 4, 200, 128, generator=g).bfloat16()
     k, v = (torch.randn(1, 1, 200, 128, generator=g).bfloat16() for _ in range(2))
     sa = torch.randn(4, generator=g) * 0.5
-    a = run_fwd(_prog("bf16", False, FwdGen), q, k, v, 4, 70, sa, "bf16")
-    b = run_fwd(_prog("bf16", True, FwdGen), q, k, v, 4, 70, sa, "bf16")
+    a = run_fwd(_prog("bf16", False, FwdGen, persist=False), q, k, v, 4, 70, sa, "bf16")
+    b = run_fwd(_prog("bf16", True, FwdGen, persist=False), q, k, v, 4, 70, sa, "bf16")
+    c = run_fwd(_prog("bf16", True, FwdGen), q, k, v, 4, 70, sa, "bf16", persist=True, n_wg=n_wg)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm assembler not installed")
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_fwd_body_assembles_for_gfx950(dtype):
-    ok, err = assemble(_prog(dtype, True, FwdGen))
+@pytest.mark.parametrize("dtype,persist", [("bf16", True), ("f16", True), ("bf16", False)])
+def test_fwd_body_assembles_for_gfx950(dtype, persist):
+    ok, err = assemble(_prog(dtype, True, FwdGen, persist=persist))
     assert ok, err[:4000]
 
 
@@ -160,11 +172,11 @@ def test_other_head_dims_in_emulator(D):
     q, k, v, do, lse, delta, dk, dv = _case(B, Hq, Hkv, N, Nk, ns, W, "bf16", seed=D, D=D)
     dq = _case.dq
     dk_e, dv_e = run_dkdv(_prog("bf16", True, DkdvGen, D), q, k, v, do, lse, delta, ns, W, "bf16")
-    dq_e = run_dq(_prog("bf16", True, DqGen, D), q, k, v, do, lse, delta, ns, W, "bf16")
+    dq_e = run_dq(_prog("bf16", True, DqGen, D), q, k, v, do, lse, delta, ns, W, "bf16", persist=True, n_wg=2)
     g = torch.Generator().manual_seed(1)
     sa = torch.randn(Hq, generator=g) * 0.5
     o_ref, lse_ref = O.sink_attention_dense(q, k, v, ns, W, sa)
-    o_e, lse_e = run_fwd(_prog("bf16", True, FwdGen, D), q, k, v, ns, W, sa, "bf16")
+    o_e, lse_e = run_fwd(_prog("bf16", True, FwdGen, D), q, k, v, ns, W, sa, "bf16", persist=True, n_wg=2)
     assert (dk_e.double() - dk).abs().max().item() < 4e-2 and (dv_e.double() - dv).abs().max().item() < 4e-2
     assert (dq_e.double() - dq).abs().max().item() < 3e-2
     assert (o_e.double() - o_ref).abs().max().item() < 1e-2 and (lse_e.double() - lse_ref).abs().max().item() < 5e-3
@@ -180,9 +192,9 @@ def test_fwd_stamped_diagnostic_body_runs_and_agrees():
     g = torch.Generator().manual_seed(9)
     q = torch.randn(1, 4, 200, 128, generator=g).bfloat16()
     k, v = (torch.randn(1, 1, 200, 128, generator=g).bfloat16() for _ in range(2))
-    a = run_fwd(_prog("bf16", True, FwdGen), q, k, v, 4, 70, None, "bf16")
+    a = run_fwd(_prog("bf16", True, FwdGen, persist=False), q, k, v, 4, 70, None, "bf16")
     st = []
-    b = run_fwd(FwdGen("bf16", stamps=True).build(), q, k, v, 4, 70, None, "bf16", stats=st, stamped=True)
+    b = run_fwd(FwdGen("bf16", stamps=True, persist=False).build(), q, k, v, 4, 70, None, "bf16", stats=st, stamped=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     rec = st[-1]["dbg"]                       # [workgroup, wave, 8]
     assert (rec[:, :, 6] > 0).all() and (rec[:, :, 7] == 0).all()

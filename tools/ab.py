@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--cfg", default="C3")
     ap.add_argument("--values", default="0,1", help="the two values of the knob to compare")
+    ap.add_argument("--combos", default="", help="instead of --which/--values: comma-separated settings, each a '+'-joined "
+                    "list of which:value pairs, e.g. 5:1,5:0+6:5,5:0+6:9 (knobs not named in a setting are reset to 0)")
     args = ap.parse_args()
     B, Hq, Hkv, N, D, ns, W, aux = CFG[args.cfg]
     dev = "cuda"
@@ -32,11 +34,22 @@ def main():
     do = torch.randn_like(q)
     lib = _native.lib()
     vals = [int(x) for x in args.values.split(",")]
+    combos = None
+    if args.combos:
+        combos = [[tuple(int(y) for y in kv.split(":")) for kv in c.split("+")] for c in args.combos.split(",")]
+        vals = list(range(len(combos)))
+        knobs = sorted({kn for c in combos for kn, _ in c})
     res = {v: [] for v in vals}
     grads = {}
     for r in range(args.rounds + 2):
         for var in vals:
-            lib.sfa_debug_set_variant(args.which, var)
+            if combos:
+                for kn in knobs:
+                    lib.sfa_debug_set_variant(kn, 0)
+                for kn, val in combos[var]:
+                    lib.sfa_debug_set_variant(kn, val)
+            else:
+                lib.sfa_debug_set_variant(args.which, var)
             ev = HipEvents(4)
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             lib.sfa_debug_set_stage_events(ev.ev, 4)
@@ -51,11 +64,16 @@ def main():
             grads[var] = (out.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone())
             q.grad = k.grad = v.grad = None
     lib.sfa_debug_set_variant(args.which, 0)
-    same = all(torch.equal(a, b) for a, b in zip(grads[vals[0]], grads[vals[1]]))
+    if combos:
+        for kn in knobs:
+            lib.sfa_debug_set_variant(kn, 0)
+    same = all(torch.equal(a, b) for v2 in vals[1:] for a, b in zip(grads[vals[0]], grads[v2]))
     for var in vals:
         cols = list(zip(*res[var]))
         med = [sorted(c)[len(c) // 2] for c in cols]
         mn = [min(c) for c in cols]
+        if combos:
+            print("setting", "+".join("%d:%d" % kv for kv in combos[var]), end=" -> ")
         print(f"variant {var}: fwd med {med[0]:.4f} min {mn[0]:.4f} | dkdv med {med[1]:.4f} min {mn[1]:.4f} | dq med {med[2]:.4f} "
               f"min {mn[2]:.4f} ms  (path {_native.last_path()})")
     print("results bitwise equal between variants:", same)

@@ -24,10 +24,21 @@ from __future__ import annotations
 from .core import A, Imm, Instr, M0, P, PV, Prog, Reg, S, V, VCC, imm
 from .dkdv import Alloc
 from .sched import finish_block, fix_hazards, insert_waits, schedule
+from .worklist import WorkList
 
 STG_BYTES = 32768
 NSTAGE = 4
 LDS_BYTES = NSTAGE * STG_BYTES
+
+# ---- persistent (work-list) form: the workgroup walks a list of work items; the HIP shell writes one 128-byte descriptor
+# per item into LDS behind the tile ring, the body reads the fields it needs with uniform ds_reads + v_readfirstlane.
+DESC_BASE = LDS_BYTES          # byte 131072 (tools/asmgen/worklist.py: descriptor size, items per invocation)
+# descriptor dwords; the K / V stream part (16 ..) has the same layout in the forward kernel's descriptor
+DESC = {"q_lo": 0, "q_hi": 1, "do_lo": 2, "do_hi": 3, "lse_lo": 4, "lse_hi": 5, "dl_lo": 6, "dl_hi": 7,
+        "dq_lo": 8, "dq_hi": 9, "q0": 10, "nrows": 11, "q_rng": 12, "do_rng": 13, "dq_rng": 14,
+        "k_lo": 16, "k_hi": 17, "v_lo": 18, "v_hi": 19, "k_rng": 20, "v_rng": 21, "nt": 22, "ts_hi": 23, "tw_off": 24}
+PARAMS_PK = ["q_hs", "q_sn", "do_hs", "do_sn", "dq_hs", "dq_sn", "k_sn", "v_sn", "ld_hs", "pos0", "W", "ns",
+             "hpw_log2", "c_log2", "nlog2e", "scale", "n_items"]
 
 PARAMS = [
     "q_lo", "q_hi", "q_hs", "q_sn", "q_rng",
@@ -42,10 +53,15 @@ PARAMS = [
 # of the workgroup; nlog2e = -log2(e) (f32 bits).
 
 
-class DqGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120):
+class DqGen(WorkList):
+    DESC, DESC_BASE = DESC, DESC_BASE
+
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
+        self.persist = persist
+        if sfirst is None:
+            sfirst = (44 if stamps else 48) if persist else 56
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dma_t0, self.dma_dt = dma_t0, dma_dt   # deadlines of the eight LDS-DMA pieces inside a trip (cycles of the model)
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
@@ -90,10 +106,33 @@ class DqGen:
         self.s_wofs = sa("s_wofs")
         self.s_cls = sa("s_cls")
         self.s_tmp = [sa("s_tmp%d" % i) for i in range(5)]
+        if persist:
+            self.wl_alloc(sa)
+        self.stamps = stamps and persist          # diagnostic build (tools/stamps_wl.py --phases): where an item transition goes
+        if self.stamps:
+            self.s_tt = sa("s_tt", 2, 2)
+            self.s_T0 = sa("s_T0")
+            self.s_acc = [sa("s_acc%d" % i) for i in range(3)]
+        # per-item tile-list scalars: SGPRs of the work-list form, asm inputs otherwise
+        self.r_nt = self.s_nt if persist else P("nt")
+        self.r_ts_hi = self.s_ts_hi if persist else P("ts_hi")
+        self.r_tw_off = self.s_tw_off if persist else P("tw_off")
         self.pool_next = 0
 
     def params(self):
-        return list(PARAMS)
+        return list(PARAMS_PK if self.persist else PARAMS) + (["dbg_lo", "dbg_hi", "bid"] if self.stamps else [])
+
+    def emit_stamp(self, p: Prog, k: int):
+        """k = -1: the reference time (item's loop ended); k >= 0: add the time since then to accumulator k"""
+        if not self.stamps:
+            return
+        p.add(Instr("s_memtime", [self.s_tt], [], kind="fence"))
+        p.s_waitcnt(lgkmcnt=0)
+        if k < 0:
+            p.s_mov(self.s_T0, self.s_tt[0])
+        else:
+            p.s_sub_u32(self.s_tmp[0], self.s_tt[0], self.s_T0)
+            p.s_add_u32(self.s_acc[k], self.s_acc[k], self.s_tmp[0])
 
     def pool(self):
         r = self.POOL[self.pool_next % len(self.POOL)]
@@ -103,8 +142,8 @@ class DqGen:
     # ------------------------------------------------------------------ pieces
     def emit_tile_of(self, p: Prog, dst, it):
         """dst = key-tile index of iteration `it` (sink tiles first, then the window tiles)"""
-        p.s_add_u32(dst, it, P("tw_off"))
-        p.s_cmp("lt_u32", it, P("ts_hi"))
+        p.s_add_u32(dst, it, self.r_tw_off)
+        p.s_cmp("lt_u32", it, self.r_ts_hi)
         p.s_cselect(dst, it, dst)
 
     def emit_dma_tile(self, p: Prog, it_reg, spread=False):
@@ -312,9 +351,12 @@ class DqGen:
     def loop_top(self) -> Prog:
         p = Prog()
         p.label("L_top%=")
-        p.s_cmp("ge_u32", self.s_it, P("nt"))
+        if self.persist:
+            self.emit_stream_advance(p)
+        p.s_cmp("ge_u32", self.s_it, self.r_nt)
         p.s_cbranch("scc1", "L_done%=")
         p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
+        p.label("L_top_b%=")
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last trip")
         p.s_cmp("eq_u32", self.s_cls, 0)
@@ -339,9 +381,12 @@ class DqGen:
         p.v_xor(self.a_tr1, 32, self.a_tr0)
         p.v_add_u32(self.a_kn_e, self.s_stn, self.l_row_e)
         p.v_xor(self.a_kn_o, 32, self.a_kn_e)
-        # fetch tile it + 3
-        p.s_add_u32(st[4], self.s_it, 3)
-        self.emit_dma_tile(p, st[4], spread=True)
+        # fetch tile it + 3 (work-list form: the next tile of the K / V stream, which may belong to the next item)
+        if self.persist:
+            self.emit_dma_stream_tile(p, spread=True)
+        else:
+            p.s_add_u32(st[4], self.s_it, 3)
+            self.emit_dma_tile(p, st[4], spread=True)
         if cls:
             for rb in range(2):      # (pos - k0 - 4 h): u = this - (32 kh + o_v) = pos - key
                 p.v_lshrrev(self.tmp[1], 5, self.lane)
@@ -465,7 +510,274 @@ class DqGen:
         p.s_waitcnt(vmcnt=0)
         return p
 
+
+    # ================================================================== work-list (persistent) form
+    def setup_pk(self) -> Prog:
+        """once per workgroup: lane constants, wave -> (head, row group), K / V stream offsets"""
+        p = Prog()
+        t0, t1, t2, t3 = self.tmp
+        st = self.s_tmp
+        lane, wv = self.lane, self.s_wave
+        p.v_and(lane, 63, PV("tid"))
+        p.v_lshrrev(t0, 6, PV("tid"))
+        p.v_readfirstlane(wv, t0)
+        p.v_and(self.lane31, 31, lane)
+        p.v_mov(self.v_oob, imm(0x7FFFF000))
+        p.s_lshl_b32(st[0], 1, P("hpw_log2"))
+        p.s_sub_u32(st[0], st[0], 1)
+        p.s_and_b32(self.s_hh, wv, st[0])
+        p.s_lshr_b32(self.s_rgi, wv, P("hpw_log2"))
+        p.v_lshrrev(t0, 3, self.lane31)
+        p.v_lshlrev(t0, 11, t0)
+        p.v_and(t1, 7, lane)
+        p.v_lshl_add_u32(t0, t1, 6, t0)
+        p.v_bfe_u32(t1, lane, 2, 2)
+        p.v_lshrrev(t2, 5, lane)                              # h
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(self.l_row_e, t1, 4, t0)
+        p.v_bfe_u32(t0, lane, 2, 2)
+        p.v_lshl_add_u32(t0, t2, 2, t0)
+        p.v_lshlrev(t0, 6, t0)
+        p.v_bfe_u32(t1, lane, 4, 1)
+        p.v_bfe_u32(t3, lane, 1, 1)
+        p.v_lshl_add_u32(t1, t1, 1, t3)
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(t0, t1, 4, t0)
+        p.v_and(t1, 1, lane)
+        p.v_lshl_add_u32(self.l_tr0, t1, 3, t0)
+        rr, slot = t0, t1
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.s_lshl_b32(st[0], wv, 4)
+        for e in range(2):
+            p.v_lshrrev(t3, 2, rr)
+            p.v_add_u32(t3, 2 * e, t3)
+            p.v_and(t3, 3, t3)
+            p.v_xor(t3, t3, slot)
+            p.v_lshl_add_u32(t3, t2, 2, t3)
+            p.v_lshlrev(t3, 4, t3)
+            p.s_add_u32(st[1], st[0], 8 * e)
+            p.v_add_u32(self.vt[0], st[1], rr)
+            for col, nm in ((0, "k"), (1, "v")):
+                p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
+                p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+                if self.l_dma1 is not None:
+                    p.v_lshrrev(self.vt[1], 4, t3)
+                    p.v_add_u32(self.l_dma1[e][col], 128, self.l_dma[e][col])
+                    p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
+                    p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
+        p.s_lshl_b32(self.s_wofs, wv, 12)
+        p.v_mov(self.v_w, P("W"))
+        p.v_mov(self.v_2e31, imm(0x80000000))
+        return p
+
+    def item_land(self):
+        """scratch VGPR quads the descriptor groups of the item being opened land in (the S^T / dP^T tiles: dead between
+        two items)"""
+        regs = [self.SACC[kh][rb][4 * i:4 * i + 4] for kh in range(2) for rb in range(2) for i in range(4)]
+        return {g: regs[g] for g in range(8)}
+
+    def emit_item_begin(self, p: Prog):
+        """open item s_item: tile-list scalars, row positions, and the requests for its Q / dO fragments and row
+        constants (into registers that are dead once the previous item's last tile is done)"""
+        land = self.item_land()
+        t0, t1, t2, t3 = self.tmp
+        st = self.s_tmp
+        self.desc_read(p, self.s_item, (0, 1, 2, 3, 5, 6), land, t0)
+        self.desc_get(p, self.s_nt, land, "nt")
+        self.desc_get(p, self.s_ts_hi, land, "ts_hi")
+        self.desc_get(p, self.s_tw_off, land, "tw_off")
+        self.desc_get(p, st[3], land, "q0")
+        self.desc_get(p, st[4], land, "nrows")
+        p.s_lshl_b32(st[0], self.s_rgi, 6)
+        p.s_add_u32(st[0], st[0], st[3])                      # qw0 = q0 + 64 rgi
+        p.s_add_u32(self.s_pw0, st[0], P("pos0"))
+        p.s_add_u32(st[1], st[0], 63)
+        p.s_sub_u32(st[2], st[4], 1)
+        p.s_min_i32(st[1], st[1], st[2])
+        p.s_add_u32(self.s_pwhi, st[1], P("pos0"))
+        p.v_add_u32(t0, st[0], self.lane31)                   # row, rb = 0
+        p.v_add_u32(self.v_pos[0], P("pos0"), t0)
+        p.v_add_u32(self.v_pos[1], 32, self.v_pos[0])
+        p.v_lshrrev(t2, 5, self.lane)                         # h
+        vl = [self.a_k_e, self.a_k_o]                         # load offsets (the bodies recompute these registers)
+        for nm, frags in (("q", self.QF), ("do", self.DOF)):
+            self.desc_get(p, self.d_y[0], land, nm + "_lo")
+            self.desc_get(p, self.d_y[1], land, nm + "_hi")
+            p.s_mul_i32(st[1], self.s_hh, P(nm + "_hs"))
+            p.s_mul_hi_u32(st[2], self.s_hh, P(nm + "_hs"))
+            p.s_add_u32(self.d_y[0], self.d_y[0], st[1])
+            p.s_addc_u32(self.d_y[1], self.d_y[1], st[2])
+            self.desc_get(p, self.d_y[2], land, nm + "_rng")
+            p.s_mov(self.d_y[3], 0x00020000)
+            p.v_mul_lo_u32(t1, t0, P(nm + "_sn"))
+            p.v_lshl_add_u32(vl[0], t2, 4, t1)                # + 16 h
+            p.s_lshl_b32(st[1], P(nm + "_sn"), 5)
+            p.v_add_u32(vl[1], st[1], vl[0])
+            for rb in range(2):
+                for ks in range(self.DK):
+                    p.buffer_load(frags[rb][ks], vl[rb], self.d_y, 0, offset=32 * ks)
+        # row constants: Delta, then LSE (the LAST loads: waiting for them covers every request of the item)
+        p.s_mul_i32(st[1], self.s_hh, P("ld_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("ld_hs"))
+        p.v_lshlrev(t1, 2, t0)                                # row * 4
+        p.v_add_u32(t3, 128, t1)
+        for nm, dst in (("dl", self.nd), ("lse", self.lse2)):
+            self.desc_get(p, self.d_y[0], land, nm + "_lo")
+            self.desc_get(p, self.d_y[1], land, nm + "_hi")
+            p.s_add_u32(self.d_y[0], self.d_y[0], st[1])
+            p.s_addc_u32(self.d_y[1], self.d_y[1], st[2])
+            p.s_lshl_b32(self.d_y[2], st[4], 2)
+            p.s_mov(self.d_y[3], 0x00020000)
+            p.buffer_load(dst[0], t1, self.d_y, 0)
+            p.buffer_load(dst[1], t3, self.d_y, 0)
+
+    def emit_item_init(self, p: Prog):
+        """accumulators, row constants in the exp2 domain (waits for every request of emit_item_begin), first K fragments
+        of the item's first tile (ring slot s_st: landed and barrier-visible), tile state"""
+        for rb in range(2):
+            for db in range(self.DB):
+                for i in range(16):
+                    p.v_accvgpr_write(self.DQ[rb][db][i], 0)
+        for rb in range(2):
+            p.v_mul_f32(self.lse2[rb], P("nlog2e"), self.lse2[rb])
+        p.v_add_u32(self.a_kn_e, self.s_st, self.l_row_e)
+        p.v_xor(self.a_kn_o, 32, self.a_kn_e)
+        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)
+        p.s_mov(self.s_it, 0)
+        self.emit_tile_state(p, self.s_it)
+
+    def prologue_pk(self) -> Prog:
+        p = self.setup_pk()
+        if self.stamps:
+            for r in self.s_acc:
+                p.s_mov(r, 0)
+        p.s_mov(self.s_st, 0)
+        p.s_mov(self.s_stn, STG_BYTES)
+        self.emit_stream_open(p)
+        p.s_mov(self.s_std, 0)
+        self.emit_dma_stream_tile(p)
+        self.emit_stream_advance(p)
+        p.s_mov(self.s_item, 0)
+        self.emit_item_begin(p)
+        for j in (1, 2):
+            p.s_mov(self.s_std, j * STG_BYTES)
+            self.emit_dma_stream_tile(p)
+            self.emit_stream_advance(p)
+        p.s_mov(self.s_std, 3 * STG_BYTES)
+        p.s_waitcnt(vmcnt=2 * 4 * self.HALVES, note="fragments, row constants, tile 0 landed (two tiles in flight)")
+        p.s_barrier()
+        self.emit_item_init(p)
+        return p
+
+    def emit_store_setup(self, p: Prog):
+        """the finished item's dQ descriptor (d_x) and row offsets (vo), before its row positions are replaced"""
+        land = self.item_land()
+        t0, t1, t2, t3 = self.tmp
+        st = self.s_tmp
+        self.desc_read(p, self.s_item, (2, 3), land, t0)
+        self.desc_get(p, self.d_x[0], land, "dq_lo")
+        self.desc_get(p, self.d_x[1], land, "dq_hi")
+        p.s_mul_i32(st[1], self.s_hh, P("dq_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("dq_hs"))
+        p.s_add_u32(self.d_x[0], self.d_x[0], st[1])
+        p.s_addc_u32(self.d_x[1], self.d_x[1], st[2])
+        self.desc_get(p, self.d_x[2], land, "dq_rng")
+        p.s_mov(self.d_x[3], 0x00020000)
+        p.v_sub_u32(t0, self.v_pos[0], P("pos0"))             # row, rb = 0
+        p.v_mul_lo_u32(t1, t0, P("dq_sn"))
+        p.v_lshrrev(t2, 5, self.lane)
+        p.v_lshl_add_u32(self.vo[0], t2, 4, t1)               # + 16 h bytes
+        p.s_lshl_b32(st[1], P("dq_sn"), 5)
+        p.v_add_u32(self.vo[1], st[1], self.vo[0])
+
+    def emit_stores(self, p: Prog):
+        """dQ[row, d] = scale * dQ^T[d, row] (as the one-item epilogue)"""
+        dt = self.dtype
+        npair = 0
+        for rb in range(2):
+            for db in range(self.DB):
+                for gp in range(2):
+                    if 32 * db + 16 * gp >= self.D:
+                        continue
+                    X, Y = self.POOL[(2 * npair) % 8], self.POOL[(2 * npair + 1) % 8]
+                    npair += 1
+                    for e in range(4):
+                        p.v_accvgpr_read(X[e], self.DQ[rb][db][8 * gp + e])
+                        p.v_accvgpr_read(Y[e], self.DQ[rb][db][8 * gp + 4 + e])
+                    for e in range(4):
+                        p.v_mul_f32(X[e], P("scale"), X[e])
+                        p.v_mul_f32(Y[e], P("scale"), Y[e])
+                    p.v_cvt_pk(dt, X[0], X[0], X[1])
+                    p.v_cvt_pk(dt, X[1], X[2], X[3])
+                    p.v_cvt_pk(dt, X[2], Y[0], Y[1])
+                    p.v_cvt_pk(dt, X[3], Y[2], Y[3])
+                    p.v_permlane32_swap(X[0], X[2])
+                    p.v_permlane32_swap(X[1], X[3])
+                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
+
+    def build_pk(self):
+        items = []
+        items += finish_block(self.prologue_pk().items)
+        items += insert_waits(self.loop_top().items)
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")):
+            body = self.tile_body(cls).items
+            items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
+            if self.do_sched:
+                body = schedule(body)
+            body = insert_waits(body)
+            body = fix_hazards(body, loop=True)
+            items += body
+            items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        # ---- item transition: the next item's requests go out BEFORE the finished item's stores are formed
+        p = Prog()
+        p.label("L_done%=")
+        p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last trip (re-read below)")
+        self.emit_stamp(p, -1)
+        self.emit_store_setup(p)
+        p.s_add_u32(self.s_item, self.s_item, 1)
+        p.s_cmp("ge_u32", self.s_item, P("n_items"))
+        p.s_cbranch("scc1", "L_last%=")
+        items += finish_block(p.items)
+        p = Prog()
+        self.emit_item_begin(p)
+        self.emit_stamp(p, 0)                    # requests of the next item issued
+        self.emit_stores(p)
+        self.emit_stamp(p, 1)                    # stores of the finished item issued
+        self.emit_item_init(p)
+        self.emit_stamp(p, 2)                    # the next item's fragments / constants have landed, first K fragments requested
+        blk = fix_hazards(insert_waits(p.items, strict_tail=True))
+        items += blk
+        # (one barrier between the finished item's last LDS reads and the first LDS-DMA of the new item's first body: the
+        # loop head's, entered behind its vmcnt wait - the stores just issued need not have drained)
+        items.append(Instr("s_branch", mods={"label": "L_top_b%="}, kind="branch"))
+        p = Prog()
+        p.label("L_last%=")
+        self.emit_stores(p)
+        p.s_waitcnt(vmcnt=0)
+        if self.stamps:      # lane 0 of every wave: the three sums + the item count, 16 bytes at dbg[(4 bid + wave) * 16]
+            st = self.s_tmp
+            t0, t1 = self.tmp[0], self.tmp[1]
+            p.s_mov(self.d_y[0], P("dbg_lo"))
+            p.s_mov(self.d_y[1], P("dbg_hi"))
+            p.s_mov(self.d_y[3], 0x00020000)
+            p.s_lshl_b32(st[0], P("bid"), 2)
+            p.s_add_u32(st[0], st[0], self.s_wave)
+            p.s_lshl_b32(st[0], st[0], 4)
+            p.s_add_u32(self.d_y[2], st[0], 16)
+            p.v_mov(t0, st[0])
+            p.v_cmp("eq_u32", 0, self.lane)
+            p.v_cndmask(t0, self.v_oob, t0)
+            for k2, src in enumerate(self.s_acc + [P("n_items")]):
+                p.v_mov(t1, src)
+                p.buffer_store(t1, t0, self.d_y, 0, offset=4 * k2)
+            p.s_waitcnt(vmcnt=0)
+        items += finish_block(p.items)
+        return items
+
     def build(self):
+        if self.persist:
+            return self.build_pk()
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)

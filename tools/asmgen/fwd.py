@@ -24,11 +24,18 @@ from __future__ import annotations
 from .core import A, Imm, Instr, M0, P, PV, Prog, Reg, S, V, VCC, fimm, imm
 from .dkdv import Alloc
 from .sched import finish_block, fix_hazards, insert_waits, schedule
+from .worklist import STREAM, WorkList
 
 STG_BYTES = 32768
 NSTAGE = 4
 LDS_BYTES = NSTAGE * STG_BYTES
 NEG_INF = 0xFF800000
+
+# ---- work-list (persistent) form, see worklist.py: one 128-byte descriptor per item in LDS behind the ring
+DESC_BASE = LDS_BYTES
+DESC = dict({"q_lo": 0, "q_hi": 1, "o_lo": 2, "o_hi": 3, "lse_lo": 4, "lse_hi": 5, "q0": 6, "nrows": 7, "q_rng": 8, "o_rng": 9,
+             "m0_0": 12, "m0_1": 13, "m0_2": 14, "m0_3": 15}, **STREAM)
+PARAMS_PK = ["q_hs", "q_sn", "o_hs", "o_sn", "k_sn", "v_sn", "ld_hs", "l0", "pos0", "W", "ns", "hpw_log2", "c_log2", "ln2", "n_items"]
 
 PARAMS = [
     "q_lo", "q_hi", "q_hs", "q_sn", "q_rng",
@@ -41,10 +48,17 @@ PARAMS = [
 ]
 
 
-class FwdGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", stamps=False, kpre=True, kpre_dl=300):
+class FwdGen(WorkList):
+    DESC, DESC_BASE = DESC, DESC_BASE
+
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", stamps=False, kpre=True, kpre_dl=300, persist=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
+        self.persist = persist
+        if persist:
+            assert lsum == "mfma" and kpre and not stamps
+        if sfirst is None:
+            sfirst = 44 if persist else 56
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
         # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
         self.D, self.DK, self.DB, self.NCH = D, D // 16, (D + 31) // 32, D // 8
@@ -101,9 +115,16 @@ class FwdGen:
         if stamps:
             self.s_tt = sa("s_tt", 2, 2)
             self.s_T = [sa("s_T%d" % i) for i in range(5)]
+        if persist:
+            self.wl_alloc(sa)
+        self.r_nt = self.s_nt if persist else P("nt")
+        self.r_ts_hi = self.s_ts_hi if persist else P("ts_hi")
+        self.r_tw_off = self.s_tw_off if persist else P("tw_off")
         self.pool_next = 0
 
     def params(self):
+        if self.persist:
+            return list(PARAMS_PK)
         return list(PARAMS) + (["dbg_lo", "dbg_hi", "bid", "t_entry"] if self.stamps else [])
 
     def emit_stamp(self, p: Prog, k: int):
@@ -119,8 +140,8 @@ class FwdGen:
 
     # ------------------------------------------------------------------ shared with dq.py (same tile ring)
     def emit_tile_of(self, p: Prog, dst, it):
-        p.s_add_u32(dst, it, P("tw_off"))
-        p.s_cmp("lt_u32", it, P("ts_hi"))
+        p.s_add_u32(dst, it, self.r_tw_off)
+        p.s_cmp("lt_u32", it, self.r_ts_hi)
         p.s_cselect(dst, it, dst)
 
     def emit_dma_tile(self, p: Prog, it_reg, spread=False):
@@ -298,7 +319,7 @@ class FwdGen:
         self.emit_tile_of(p, t[4], t[3])
         p.s_lshl_b32(self.s_k0n, t[4], 6)
         self.emit_class(p, self.s_k0n)
-        p.s_cmp("lt_u32", t[3], P("nt"))
+        p.s_cmp("lt_u32", t[3], self.r_nt)
         p.s_cselect(self.s_cls, self.s_cls, 3)
         p.s_and_b32(t[0], it_next, 1)
         p.s_lshl_b32(t[0], t[0], 2)
@@ -456,7 +477,9 @@ class FwdGen:
         """common path: exit test, rescale test, wait + barrier, dispatch (the full-tile bodies are tested first)"""
         p = Prog()
         p.label("L_top%=")
-        p.s_cmp("ge_u32", self.s_it, P("nt"))
+        if self.persist:
+            self.emit_stream_advance(p)
+        p.s_cmp("ge_u32", self.s_it, self.r_nt)
         p.s_cbranch("scc1", "L_done%=")
         p.s_cmp_lg_u64(self.s_flag, 0)
         p.s_cbranch("scc1", "L_rescale%=")
@@ -506,8 +529,11 @@ class FwdGen:
             p.v_xor(self.a_k_o, 32, self.a_k_e)
         p.v_add_u32(self.a_tr0, self.s_st, self.l_tr0)
         p.v_xor(self.a_tr1, 32, self.a_tr0)
-        p.s_add_u32(st[4], self.s_it, 3)
-        self.emit_dma_tile(p, st[4], spread=True)
+        if self.persist:         # the next tile of the K / V stream (it may belong to the next item)
+            self.emit_dma_stream_tile(p, spread=True)
+        else:
+            p.s_add_u32(st[4], self.s_it, 3)
+            self.emit_dma_tile(p, st[4], spread=True)
         if cls_next != 3:
             self.emit_A(p, par ^ 1, self.a_k_e, self.a_k_o, pre=self.kpre)
         self.emit_E(p, par)
@@ -635,7 +661,297 @@ class FwdGen:
             p.s_waitcnt(vmcnt=0)
         return p
 
+
+    # ================================================================== work-list (persistent) form
+    def setup_pk(self) -> Prog:
+        """once per workgroup: lane constants, wave -> (head, row group), K / V stream offsets, constants"""
+        p = Prog()
+        t0, t1, t2, t3 = self.tmp[:4]
+        st = self.s_tmp
+        lane, wv = self.lane, self.s_wave
+        p.v_and(lane, 63, PV("tid"))
+        p.v_lshrrev(t0, 6, PV("tid"))
+        p.v_readfirstlane(wv, t0)
+        p.v_and(self.lane31, 31, lane)
+        p.v_mov(self.v_oob, imm(0x7FFFF000))
+        p.s_lshl_b32(st[0], 1, P("hpw_log2"))
+        p.s_sub_u32(st[0], st[0], 1)
+        p.s_and_b32(self.s_hh, wv, st[0])
+        p.s_lshr_b32(self.s_rgi, wv, P("hpw_log2"))
+        p.v_lshrrev(t0, 3, self.lane31)
+        p.v_lshlrev(t0, 11, t0)
+        p.v_and(t1, 7, lane)
+        p.v_lshl_add_u32(t0, t1, 6, t0)
+        p.v_bfe_u32(t1, lane, 2, 2)
+        p.v_lshrrev(t2, 5, lane)                              # h
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(self.l_row_e, t1, 4, t0)
+        p.v_bfe_u32(t0, lane, 2, 2)
+        p.v_lshl_add_u32(t0, t2, 2, t0)
+        p.v_lshlrev(t0, 6, t0)
+        p.v_bfe_u32(t1, lane, 4, 1)
+        p.v_bfe_u32(t3, lane, 1, 1)
+        p.v_lshl_add_u32(t1, t1, 1, t3)
+        p.v_xor(t1, t1, t2)
+        p.v_lshl_add_u32(t0, t1, 4, t0)
+        p.v_and(t1, 1, lane)
+        p.v_lshl_add_u32(self.l_tr0, t1, 3, t0)
+        rr, slot = t0, t1
+        p.v_bfe_u32(rr, lane, 2, 3)
+        p.v_and(slot, 3, lane)
+        p.s_lshl_b32(st[0], wv, 4)
+        for e in range(2):
+            p.v_lshrrev(t3, 2, rr)
+            p.v_add_u32(t3, 2 * e, t3)
+            p.v_and(t3, 3, t3)
+            p.v_xor(t3, t3, slot)
+            p.v_lshl_add_u32(t3, t2, 2, t3)
+            p.v_lshlrev(t3, 4, t3)
+            p.s_add_u32(st[1], st[0], 8 * e)
+            p.v_add_u32(self.vt[0], st[1], rr)
+            for col, nm in ((0, "k"), (1, "v")):
+                p.v_mul_lo_u32(self.l_dma[e][col], self.vt[0], P(nm + "_sn"))
+                p.v_add_u32(self.l_dma[e][col], self.l_dma[e][col], t3)
+                if self.l_dma1 is not None:
+                    p.v_lshrrev(self.vt[1], 4, t3)
+                    p.v_add_u32(self.l_dma1[e][col], 128, self.l_dma[e][col])
+                    p.v_cmp("gt_u32", self.NCH - 8, self.vt[1])
+                    p.v_cndmask(self.l_dma1[e][col], self.v_oob, self.l_dma1[e][col])
+        p.s_lshl_b32(self.s_wofs, wv, 12)
+        ones = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
+        p.v_mov(t1, imm(ones))
+        for i in range(4):
+            p.v_accvgpr_write(self.ONES[i], t1)
+        p.v_mov(self.v_w, P("W"))
+        p.v_mov(self.v_2e31, imm(0x80000000))
+        p.v_mov(self.v_ninf, imm(NEG_INF))
+        return p
+
+    def land_new(self):
+        """scratch VGPR quads for the descriptor groups of the item being opened (S^T tile registers of parity 1: dead
+        between two items; the pipeline fill of the new item writes parity 0)"""
+        regs = [self.SS[1][0][rb][4 * i:4 * i + 4] for rb in range(2) for i in range(4)]
+        return {g: regs[g] for g in range(8)}
+
+    def land_old(self):
+        regs = [self.SS[1][1][0][4 * i:4 * i + 4] for i in range(4)]
+        return {g: regs[g] for g in range(4)}
+
+    def emit_item_begin(self, p: Prog):
+        """open item s_item: tile-list scalars, row positions, the requests for its Q fragments (into registers that are
+        dead once the previous item's last S^T chains have run)"""
+        land = self.land_new()
+        t0, t1, t2, t3 = self.tmp[:4]
+        st = self.s_tmp
+        self.desc_read(p, self.s_item, (0, 1, 2, 3, 5, 6), land, t0)
+        self.desc_get(p, self.s_nt, land, "nt")
+        self.desc_get(p, self.s_ts_hi, land, "ts_hi")
+        self.desc_get(p, self.s_tw_off, land, "tw_off")
+        self.desc_get(p, st[3], land, "q0")
+        self.desc_get(p, st[4], land, "nrows")
+        p.s_lshl_b32(st[0], self.s_rgi, 6)
+        p.s_add_u32(st[0], st[0], st[3])                      # qw0 = q0 + 64 rgi
+        p.s_add_u32(self.s_pw0, st[0], P("pos0"))
+        p.s_add_u32(st[1], st[0], 63)
+        p.s_sub_u32(st[2], st[4], 1)
+        p.s_min_i32(st[1], st[1], st[2])
+        p.s_add_u32(self.s_pwhi, st[1], P("pos0"))
+        p.v_add_u32(t0, st[0], self.lane31)                   # row, rb = 0
+        p.v_add_u32(self.v_pos[0], P("pos0"), t0)
+        p.v_add_u32(self.v_pos[1], 32, self.v_pos[0])
+        p.v_lshrrev(t2, 5, self.lane)                         # h
+        vl = [self.a_tr0, self.a_tr1]                         # load offsets (the bodies recompute these registers)
+        self.desc_get(p, self.d_y[0], land, "q_lo")
+        self.desc_get(p, self.d_y[1], land, "q_hi")
+        p.s_mul_i32(st[1], self.s_hh, P("q_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("q_hs"))
+        p.s_add_u32(self.d_y[0], self.d_y[0], st[1])
+        p.s_addc_u32(self.d_y[1], self.d_y[1], st[2])
+        self.desc_get(p, self.d_y[2], land, "q_rng")
+        p.s_mov(self.d_y[3], 0x00020000)
+        p.v_mul_lo_u32(t1, t0, P("q_sn"))
+        p.v_lshl_add_u32(vl[0], t2, 4, t1)
+        p.s_lshl_b32(st[1], P("q_sn"), 5)
+        p.v_add_u32(vl[1], st[1], vl[0])
+        for rb in range(2):
+            for ks in range(self.DK):
+                p.buffer_load(self.QF[rb][ks], vl[rb], self.d_y, 0, offset=32 * ks)
+
+    def emit_item_init(self, p: Prog, first=False):
+        """softmax state of the new item (m = the head's s_aux logit or -inf, l = l0, O = 0), then the pipeline fill: S^T
+        of its tile 0 (ring slot s_st: landed and barrier-visible; waits for the Q fragments) and that tile's softmax
+        bookkeeping, the first K fragments of its tile 1"""
+        land = self.land_new()
+        st = self.s_tmp
+        for i in range(4):
+            self.desc_get(p, st[i], land, "m0_%d" % i)
+        p.s_cmp("eq_u32", self.s_hh, 1)
+        p.s_cselect(st[0], st[1], st[0])
+        p.s_cmp("eq_u32", self.s_hh, 2)
+        p.s_cselect(st[0], st[2], st[0])
+        p.s_cmp("eq_u32", self.s_hh, 3)
+        p.s_cselect(st[0], st[3], st[0])
+        for rb in range(2):
+            p.v_mov(self.m[rb], st[0])
+            for i in range(16):
+                p.v_accvgpr_write(self.LACC[rb][i], P("l0"))
+            for db in range(self.DB):
+                for i in range(16):
+                    p.v_accvgpr_write(self.OACC[rb][db][i], 0)
+        p.v_add_u32(self.a_k_e, self.s_st, self.l_row_e)
+        p.v_xor(self.a_k_o, 32, self.a_k_e)
+        self.pool_next = 0
+        self.emit_A(p, 0, self.a_k_e, self.a_k_o)
+        p.s_mov(st[3], 0)
+        self.emit_tile_of(p, st[4], st[3])
+        p.s_lshl_b32(self.s_k0n, st[4], 6)
+        self.emit_M(p, 0, 2, self.s_k0n)
+        p.s_mov(self.s_it, 0)
+        self.emit_next_class(p, self.s_it)
+        if first:
+            p.s_waitcnt(vmcnt=0, note="tiles 1, 2 landed (own pieces)")
+            p.s_barrier()
+        p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
+        p.v_xor(self.a_k_o, 32, self.a_k_e)
+        self.emit_k_prefetch(p, self.a_k_e, self.a_k_o)
+
+    def prologue_pk(self) -> Prog:
+        p = self.setup_pk()
+        p.s_mov(self.s_st, 0)
+        p.s_mov(self.s_stn, STG_BYTES)
+        self.emit_stream_open(p)
+        p.s_mov(self.s_std, 0)
+        self.emit_dma_stream_tile(p)
+        self.emit_stream_advance(p)
+        p.s_mov(self.s_item, 0)
+        self.emit_item_begin(p)
+        for j in (1, 2):
+            p.s_mov(self.s_std, j * STG_BYTES)
+            self.emit_dma_stream_tile(p)
+            self.emit_stream_advance(p)
+        p.s_mov(self.s_std, 3 * STG_BYTES)
+        p.s_waitcnt(vmcnt=2 * 4 * self.HALVES, note="Q fragments, tile 0 landed (two tiles in flight)")
+        p.s_barrier()
+        self.emit_item_init(p, first=True)
+        return p
+
+    def emit_store_setup(self, p: Prog):
+        """the finished item's O descriptor (d_x), row offsets (vo) and LSE offsets (v_d), before its row positions are
+        replaced; its descriptor groups stay in land_old() for the LSE stores"""
+        land = self.land_old()
+        t0, t1, t2, t3 = self.tmp[:4]
+        st = self.s_tmp
+        self.desc_read(p, self.s_item, (0, 1, 2), land, t0)
+        self.desc_get(p, self.d_x[0], land, "o_lo")
+        self.desc_get(p, self.d_x[1], land, "o_hi")
+        p.s_mul_i32(st[1], self.s_hh, P("o_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("o_hs"))
+        p.s_add_u32(self.d_x[0], self.d_x[0], st[1])
+        p.s_addc_u32(self.d_x[1], self.d_x[1], st[2])
+        self.desc_get(p, self.d_x[2], land, "o_rng")
+        p.s_mov(self.d_x[3], 0x00020000)
+        p.v_sub_u32(t0, self.v_pos[0], P("pos0"))             # row, rb = 0
+        p.v_mul_lo_u32(t1, t0, P("o_sn"))
+        p.v_lshrrev(t2, 5, self.lane)
+        p.v_lshl_add_u32(self.vo[0], t2, 4, t1)
+        p.s_lshl_b32(st[1], P("o_sn"), 5)
+        p.v_add_u32(self.vo[1], st[1], self.vo[0])
+        # LSE [head, row] f32: lanes 0..31 of each row block (the others: an out-of-range offset)
+        p.v_lshlrev(t1, 2, t0)
+        p.v_mov(t3, imm(0x7FFFFFF0))
+        p.v_cmp("gt_u32", 32, self.lane)
+        p.v_cndmask(self.v_d[0], t3, t1)
+        p.v_add_u32(self.v_d[1], 128, self.v_d[0])
+
+    def emit_stores(self, p: Prog):
+        """O[row, d] = O^T[d, row] / l (l = 0 -> 1), LSE = ln2 (m + log2 l) of the finished item (as the one-item epilogue)"""
+        dt = self.dtype
+        t0, t1, t2, t3, t4, t5 = self.tmp
+        st = self.s_tmp
+        land = self.land_old()
+        inv = [self.alpha[0], self.alpha[1]]
+        lg = [self.nms[0], self.nms[1]]
+        for rb in range(2):
+            p.v_accvgpr_read(t3, self.LACC[rb][0])
+            p.v_mov(t4, fimm(1.0))
+            p.v_cmp("eq_f32", 0, t3)
+            p.v_cndmask(t3, t3, t4)
+            p.v_rcp_f32(inv[rb], t3)
+            p.v_log_f32(lg[rb], t3)
+            p.v_add_f32(lg[rb], self.m[rb], lg[rb])
+            p.v_mul_f32(lg[rb], P("ln2"), lg[rb])
+        npair = 0
+        for rb in range(2):
+            for db in range(self.DB):
+                for gp in range(2):
+                    if 32 * db + 16 * gp >= self.D:
+                        continue
+                    X, Y = self.POOL[(2 * npair) % 8], self.POOL[(2 * npair + 1) % 8]
+                    npair += 1
+                    for e in range(4):
+                        p.v_accvgpr_read(X[e], self.OACC[rb][db][8 * gp + e])
+                        p.v_accvgpr_read(Y[e], self.OACC[rb][db][8 * gp + 4 + e])
+                    for e in range(4):
+                        p.v_mul_f32(X[e], inv[rb], X[e])
+                        p.v_mul_f32(Y[e], inv[rb], Y[e])
+                    p.v_cvt_pk(dt, X[0], X[0], X[1])
+                    p.v_cvt_pk(dt, X[1], X[2], X[3])
+                    p.v_cvt_pk(dt, X[2], Y[0], Y[1])
+                    p.v_cvt_pk(dt, X[3], Y[2], Y[3])
+                    p.v_permlane32_swap(X[0], X[2])
+                    p.v_permlane32_swap(X[1], X[3])
+                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
+        self.desc_get(p, self.d_x[0], land, "lse_lo")
+        self.desc_get(p, self.d_x[1], land, "lse_hi")
+        p.s_mul_i32(st[1], self.s_hh, P("ld_hs"))
+        p.s_mul_hi_u32(st[2], self.s_hh, P("ld_hs"))
+        p.s_add_u32(self.d_x[0], self.d_x[0], st[1])
+        p.s_addc_u32(self.d_x[1], self.d_x[1], st[2])
+        self.desc_get(p, st[0], land, "nrows")
+        p.s_lshl_b32(self.d_x[2], st[0], 2)
+        p.buffer_store(lg[0], self.v_d[0], self.d_x, 0)
+        p.buffer_store(lg[1], self.v_d[1], self.d_x, 0)
+
+    def build_pk(self):
+        items = []
+        items += finish_block(self.prologue_pk().items)
+        items += insert_waits(self.loop_top().items)
+        for par in range(2):
+            for cls in range(4):
+                b = self.body(par, cls).items
+                items.append(Instr("label", mods={"label": "L_body%d%%=" % (4 * par + cls)}, kind="label", cost=0))
+                if self.do_sched:
+                    b = schedule(b)
+                b = insert_waits(b)
+                b = fix_hazards(b, loop=True)
+                items += b
+                items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        items += finish_block(self.rescale().items)
+        # ---- item transition: the next item's Q requests go out BEFORE the finished item's stores are formed
+        p = Prog()
+        p.label("L_done%=")
+        p.s_waitcnt(lgkmcnt=0, note="the K fragments fetched at the end of the last iteration (re-read below)")
+        self.emit_store_setup(p)
+        p.s_add_u32(self.s_item, self.s_item, 1)
+        p.s_cmp("ge_u32", self.s_item, P("n_items"))
+        p.s_cbranch("scc1", "L_last%=")
+        items += finish_block(p.items)
+        p = Prog()
+        self.emit_item_begin(p)
+        self.emit_stores(p)
+        self.emit_item_init(p)
+        items += fix_hazards(insert_waits(p.items, strict_tail=True))
+        items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        p = Prog()
+        p.label("L_last%=")
+        self.emit_stores(p)
+        p.s_waitcnt(vmcnt=0)
+        items += finish_block(p.items)
+        return items
+
     def build(self):
+        if self.persist:
+            return self.build_pk()
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)

@@ -113,8 +113,49 @@ def dq_block_params(N, Nk, ns, window, g, qt, hpw):
     return dict(P=P, W=W, q0=q0, ts_hi=ts_hi, tw_off=tw_lo - ts_hi, nt=ts_hi + (tw_hi - tw_lo), BM=BM)
 
 
-def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, stats=None):
-    """q, do [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; lse, delta [B, Hq, N].  Returns dq [B, Hq, N, D] float32."""
+def worklist_of(n_ranks, n_wg, w):
+    """ranks (cost-descending item order) of workgroup w of n_wg, in processing order: snake over the rounds (round j
+    hands rank j n_wg + pos to the workgroup; pos runs forwards in even rounds, backwards in odd ones, inside the
+    workgroup's XCD lane w % 8 when the grid is a multiple of 8) - the HIP shells' rule (csrc/sfa_worklist.hpp)"""
+    out = []
+    j = 0
+    while j * n_wg < n_ranks:
+        if j & 1:
+            pos = ((n_wg // 8 - 1 - w // 8) * 8 + w % 8) if n_wg % 8 == 0 else n_wg - 1 - w
+        else:
+            pos = w
+        r = j * n_wg + pos
+        if r < n_ranks:
+            out.append(r)
+        j += 1
+    return out
+
+
+def run_worklist(prog, mem, all_items, consts, desc_map, desc_base, n_wg, check_races=True, stats=None):
+    """all_items: per rank a dict of descriptor fields or None (an empty item: skipped, as the shell's compaction does);
+    runs n_wg persistent workgroups"""
+    for w in range(n_wg):
+        mine = [all_items[r] for r in worklist_of(len(all_items), n_wg, w) if all_items[r] is not None]
+        if not mine:
+            continue
+        assert len(mine) <= 256
+        params = dict(consts, n_items=len(mine))
+        wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+        tab = np.zeros((len(mine), 32), dtype=np.uint32)
+        for i, it in enumerate(mine):
+            assert set(it) == set(desc_map), set(it) ^ set(desc_map)
+            for name, val in it.items():
+                tab[i, desc_map[name]] = int(val) & 0xFFFFFFFF
+        raw = tab.view(np.uint8).reshape(-1)
+        wg.lds[desc_base:desc_base + raw.size] = raw
+        wg.run()
+        if stats is not None:
+            stats.append({"wg": w, "n_items": len(mine), "icount": [x.icount for x in wg.waves]})
+
+
+def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, stats=None, persist=False, n_wg=3):
+    """q, do [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; lse, delta [B, Hq, N].  Returns dq [B, Hq, N, D] float32.
+    persist: the work-list form of the body (n_wg persistent workgroups share the items)."""
     from . import dq as KQ
     B, Hq, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
@@ -128,6 +169,35 @@ def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=
     adq = mem.alloc_zero(B * Hq * N * D * 2)
     BM = 64 * (4 // hpw)
     nqt = (N + BM - 1) // BM
+    if persist:
+        rng_q = ((N - 1) * D + D) * 2
+        rng_k = ((Nk - 1) * D + D) * 2
+        lo = lambda x: x & 0xFFFFFFFF
+        ngrp = B * Hkv * (g // hpw)
+        all_items = []
+        for r in range(nqt * ngrp):                      # rank -> (query tile, descending; group)
+            qt, grp = nqt - 1 - r // ngrp, r % ngrp
+            hg = grp % (g // hpw)
+            hk = (grp // (g // hpw)) % Hkv
+            b = grp // (g // hpw) // Hkv
+            bp = dq_block_params(N, Nk, ns, window, g, qt, hpw)
+            head0 = hk * g + hg * hpw
+            hb = (b * Hq + head0) * N
+            kb = (b * Hkv + hk) * Nk * D * 2
+            all_items.append(dict(
+                q_lo=lo(aq + hb * D * 2), q_hi=(aq + hb * D * 2) >> 32, do_lo=lo(ado + hb * D * 2), do_hi=(ado + hb * D * 2) >> 32,
+                lse_lo=lo(alse + hb * 4), lse_hi=(alse + hb * 4) >> 32, dl_lo=lo(adl + hb * 4), dl_hi=(adl + hb * 4) >> 32,
+                dq_lo=lo(adq + hb * D * 2), dq_hi=(adq + hb * D * 2) >> 32, q0=bp["q0"], nrows=N,
+                q_rng=rng_q, do_rng=rng_q, dq_rng=rng_q,
+                k_lo=lo(ak + kb), k_hi=(ak + kb) >> 32, v_lo=lo(av + kb), v_hi=(av + kb) >> 32, k_rng=rng_k, v_rng=rng_k,
+                nt=bp["nt"], ts_hi=bp["ts_hi"], tw_off=bp["tw_off"]))
+        consts = dict(q_hs=N * D * 2, q_sn=D * 2, do_hs=N * D * 2, do_sn=D * 2, dq_hs=N * D * 2, dq_sn=D * 2,
+                      k_sn=D * 2, v_sn=D * 2, ld_hs=N * 4, pos0=Nk - N, W=min(max(window, 0), Nk), ns=ns,
+                      hpw_log2={1: 0, 2: 1, 4: 2}[hpw], c_log2=f32_bits(scale * math.log2(math.e)),
+                      nlog2e=f32_bits(-math.log2(math.e)), scale=f32_bits(scale))
+        assert set(consts) | {"n_items"} == set(KQ.PARAMS_PK)
+        run_worklist(prog, mem, all_items, consts, KQ.DESC, KQ.DESC_BASE, n_wg, check_races, stats)
+        nqt = 0                                          # (skip the one-item loop below)
     for b in range(B):
         for hk in range(Hkv):
             for hg in range(g // hpw):
@@ -160,8 +230,9 @@ def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=
 
 
 # ------------------------------------------------------------------------------------------------ forward kernel
-def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=True, stats=None, stamped=False):
-    """q [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; s_aux [Hq] or None.  Returns o [B, Hq, N, D] float32, lse [B, Hq, N]."""
+def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=True, stats=None, stamped=False, persist=False, n_wg=3):
+    """q [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; s_aux [Hq] or None.  Returns o [B, Hq, N, D] float32, lse [B, Hq, N].
+    persist: the work-list form of the body (n_wg persistent workgroups share the items)."""
     from . import fwd as KF
     B, Hq, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
@@ -177,6 +248,34 @@ def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=Tru
     nqt = (N + BM - 1) // BM
     dbg = mem.alloc_zero(B * Hkv * (g // hpw) * nqt * 128) if stamped else None     # stamped diagnostic body: 32 bytes per wave
     bid = 0
+    if persist:
+        rng_q = ((N - 1) * D + D) * 2
+        rng_k = ((Nk - 1) * D + D) * 2
+        lo = lambda x: x & 0xFFFFFFFF
+        ngrp = B * Hkv * (g // hpw)
+        all_items = []
+        for r in range(nqt * ngrp):
+            qt, grp = nqt - 1 - r // ngrp, r % ngrp
+            hg = grp % (g // hpw)
+            hk = (grp // (g // hpw)) % Hkv
+            b = grp // (g // hpw) // Hkv
+            bp = dq_block_params(N, Nk, ns, window, g, qt, hpw)
+            head0 = hk * g + hg * hpw
+            hb = (b * Hq + head0) * N
+            kb = (b * Hkv + hk) * Nk * D * 2
+            m0 = [f32_bits(float(s_aux[head0 + i]) * log2e) if (s_aux is not None and i < hpw) else KF.NEG_INF for i in range(4)]
+            all_items.append(dict(
+                q_lo=lo(aq + hb * D * 2), q_hi=(aq + hb * D * 2) >> 32, o_lo=lo(ao + hb * D * 2), o_hi=(ao + hb * D * 2) >> 32,
+                lse_lo=lo(alse + hb * 4), lse_hi=(alse + hb * 4) >> 32, q0=bp["q0"], nrows=N, q_rng=rng_q, o_rng=rng_q,
+                m0_0=m0[0], m0_1=m0[1], m0_2=m0[2], m0_3=m0[3],
+                k_lo=lo(ak + kb), k_hi=(ak + kb) >> 32, v_lo=lo(av + kb), v_hi=(av + kb) >> 32, k_rng=rng_k, v_rng=rng_k,
+                nt=bp["nt"], ts_hi=bp["ts_hi"], tw_off=bp["tw_off"]))
+        consts = dict(q_hs=N * D * 2, q_sn=D * 2, o_hs=N * D * 2, o_sn=D * 2, k_sn=D * 2, v_sn=D * 2, ld_hs=N * 4,
+                      l0=f32_bits(1.0 if s_aux is not None else 0.0), pos0=Nk - N, W=min(max(window, 0), Nk), ns=ns,
+                      hpw_log2={1: 0, 2: 1, 4: 2}[hpw], c_log2=f32_bits(scale * log2e), ln2=f32_bits(math.log(2.0)))
+        assert set(consts) | {"n_items"} == set(KF.PARAMS_PK)
+        run_worklist(prog, mem, all_items, consts, KF.DESC, KF.DESC_BASE, n_wg, check_races, stats)
+        nqt = 0
     for b in range(B):
         for hk in range(Hkv):
             for hg in range(g // hpw):

@@ -229,7 +229,8 @@ def insert_waits(items: Sequence[Instr], strict: bool = False, strict_tail: bool
     """Insert counted s_waitcnt lgkmcnt(N) / vmcnt(N) in front of every instruction that touches a register with an
     outstanding ds_read / buffer_load into it.  LDS ops complete in order, so do vector memory ops (loads, stores
     and LDS-DMA share the vmcnt queue).  Hand-written waits in `items` are honoured (they shorten the queues).
-    Labels and branches: the bookkeeping restarts empty there (`strict`: register loads outstanding there are an error)."""
+    Labels and branches: the bookkeeping restarts empty there (`strict`: register loads outstanding there are an error;
+    `strict_tail`: a global load into a register still outstanding at the END of the list is an error)."""
     out: List[Instr] = []
     lgkm: List[set] = []      # outstanding LDS ops, oldest first: set of destination registers (may be empty)
     vm: List[set] = []
@@ -288,6 +289,8 @@ def insert_waits(items: Sequence[Instr], strict: bool = False, strict_tail: bool
         if len(vm) > 63:
             del vm[:len(vm) - 63]
         out.append(it)
+    if strict_tail and any(vm):
+        raise RuntimeError("global load into a register outstanding at the end of the block")
     return out
 
 
