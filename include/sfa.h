@@ -18,13 +18,17 @@
  *
  * Conventions
  *   - Plain C: pointers, sizes, ints.  No torch / C++ types cross the boundary.
- *   - The library never allocates, frees or synchronises.  The caller owns every
+ *   - The library never allocates or frees device memory and never synchronises.  The caller owns every
  *     buffer (outputs and workspaces included) and passes DEVICE pointers.
  *   - Every launch goes to the hipStream_t passed as `stream` (void* here so the
- *     header needs no HIP include); the caller makes the right device current.
- *   - Re-entrant.  Mutable state inside the library: the thread-local error / path strings, a per-kernel bitmask of
- *     the devices whose dynamic-LDS attribute has been set (atomic OR, idempotent) and the tuning knobs read once from
- *     the environment (SFA_*) at first use.  Nothing else survives a call.
+ *     header needs no HIP include); the caller makes the right device current.  One documented exception, opt-in per
+ *     call: with SFA_FLAG_BWD_OVERLAP sfa_bwd may put its dQ kernel on a library-owned side stream (see the flag).
+ *   - Re-entrant.  Mutable state inside the library, all of it listed here: the thread-local error / path strings; a
+ *     per-kernel bitmask of the devices whose dynamic-LDS attribute has been set (atomic OR, idempotent); and, only
+ *     for callers that pass SFA_FLAG_BWD_OVERLAP, one side stream + two events per (calling thread, device), created
+ *     at that thread's first overlapped sfa_bwd on the device and destroyed when the thread ends.  Nothing else
+ *     survives a call.  A RELEASE build reads no environment variable and ignores sfa_debug_set_variant: the SFA_*
+ *     tuning knobs and the A/B variants exist in -DSFA_AB development builds only (tools/ab.py, tools/build_ab.sh).
  *   - Return value: 0 = ok, <0 = SFA_ERR_* (argument / support problem, nothing
  *     was launched), >0 = a hipError_t from a launch.
  *   - Tensors are described by sfa_tensor: 4-D [B, H, N, D] with strides in
@@ -41,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SFA_ABI_VERSION 1
+#define SFA_ABI_VERSION 2
 
 /* element types of q/k/v/o/do/dq/dk/dv (all tensors of one call share one dtype) */
 #define SFA_DTYPE_F32 0
@@ -62,6 +66,22 @@ extern "C" {
  * align256((B * Hkv + 1) * 4) bytes once; the kernel leaves them zero.  Worth it at small batch, where a decode step is
  * two ~10 us launches otherwise. */
 #define SFA_FLAG_DECODE_ONE_PASS 0x4u
+/* sfa_bwd / sfa_bwd_varlen: the dQ and dK/dV kernels are independent; on a SMALL grid (dQ grid below 4 workgroups per
+ * CU: batch 1, tensor- or sequence-parallel shards) the dQ kernel is launched on a library-owned side stream of the
+ * lowest queue priority, forked from and joined back into `stream` by events, so that it fills the CUs the dK/dV
+ * kernel leaves idle (+1.4 ... 17 %).  Capturable (fork / join are event edges), EXCEPT that the side stream itself
+ * cannot be created under capture: a thread whose FIRST overlapped call on a device happens while `stream` is being
+ * captured runs that call (and every later captured one, until an uncaptured call has created the stream) without
+ * overlap.  Every return path behind the fork joins the side stream again.  Without the flag every launch goes to
+ * `stream` and the library creates nothing.  sink_attention (Python) sets it by default. */
+#define SFA_FLAG_BWD_OVERLAP 0x8u
+/* sfa_bwd / sfa_bwd_varlen / sfa_bwd_workspace_bytes: dispatch override of the dK/dV kernel for head dims 64 ... 128
+ * (pass the same bits to the workspace query): _ASM = the hand-placed 256-key-block kernel wherever its body serves the
+ * shape, _WS = the wave-specialised compiled kernel (128-key blocks).  Neither: the library's rule (hand-placed for
+ * dense self-attention batches and for grids that fill the chip).  The parity tests run every backward case under the
+ * rule AND with the hand-placed kernel forced. */
+#define SFA_FLAG_BWD_DKDV_ASM 0x10u
+#define SFA_FLAG_BWD_DKDV_WS 0x20u
 
 typedef struct sfa_tensor {
     void* ptr;         /* device pointer to element [0,0,0,0]                    */
@@ -89,10 +109,11 @@ const char* sfa_last_path(void);
  * Process-global and not thread-safe by design: a diagnostic, never used by the op itself.
  */
 /* Development hook: in a library built with -DSFA_AB two variants of a kernel body are compiled side by side and
- * `value` picks the one `which` (0 dK/dV, 1 forward, 2 dQ) launches, so that tools/ab.py can time them alternately in
- * one process on one device.  No effect in a release build. */
+ * `value` picks the one `which` (0 dK/dV, 1 forward, 2 dQ) launches; 3 = workgroup order of the dK/dV kernel, 7 = its
+ * ticketed dispatch off - so that tools/ab.py can time them alternately in one process on one device.  A release
+ * build stores the value and never reads it: no effect on dispatch (use the SFA_FLAG_BWD_DKDV_* bits for that). */
 int sfa_debug_set_variant(int which, int value);
-/* Device buffer for the cycle stamps of a diagnostic build (tools/stamps_dkdv.py); unused otherwise. */
+/* Device buffer for the cycle stamps of a diagnostic build (tools/stamps_dkdv.py, tools/stamps_wl.py); unused otherwise. */
 int sfa_debug_set_ptr(void* device_buffer);
 int sfa_debug_set_stage_events(void* const* events, int count);
 

@@ -13,7 +13,7 @@ static char g_path[128] = "";  // diagnostic only: last kernel family dispatched
 
 // measurement hook (sfa_debug_set_stage_events): process-global on purpose, the autograd thread runs sfa_bwd
 void* g_debug_ptr = nullptr;
-int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sfa_debug_set_variant: A/B builds (-DSFA_AB) only
+int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sfa_debug_set_variant: read by A/B builds (-DSFA_AB) only
 static void* const* g_stage_events = nullptr;
 static int g_stage_count = 0;
 bool stage_events_armed() { return g_stage_events != nullptr; }
@@ -193,7 +193,7 @@ int sfa_bwd(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, const
     // the row constants of the dK/dV kernel come out of the same pass whenever it is the vectorised one
     const bool fuse = use_mfma && bwd_mfma_wants_consts() && bwd_preprocess_vectorised(o, d_o, p);
     st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s,
-                        fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr, bwd_mfma_lse_factor(p));
+                        fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr, bwd_mfma_lse_factor(p, flags));
     record_stage(1, s);
     if (st) return st;
     if (use_mfma)
@@ -279,10 +279,10 @@ int sfa_bwd_varlen(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v
     const bool fuse = bwd_mfma_wants_consts() && bwd_preprocess_vectorised(o, d_o, p);
     st = bwd_preprocess(o, d_o, lse, s_aux, delta, dsaux_part, ds_aux, p, s,           // row-wise: no sequence structure
                         fuse ? reinterpret_cast<float*>((char*)workspace + w.mfma_off) : nullptr,
-                        bwd_mfma_lse_factor(run));   // (the LAUNCH problem: the kernel choice clamps the window to max_seqlen)
+                        bwd_mfma_lse_factor(run, flags));   // (the LAUNCH problem: the kernel choice clamps the window to max_seqlen)
     record_stage(1, s);
     if (st) return st;
-    st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, run, 0, s, fuse);
+    st = bwd_mfma(q, k, v, d_o, lse, delta, dq, dk, dv, (char*)workspace + w.mfma_off, run, flags, s, fuse);
     record_stage(3, s);
     return st;
 }

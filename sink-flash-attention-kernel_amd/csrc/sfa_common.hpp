@@ -20,8 +20,13 @@ void set_path(const char* fmt, ...);
 void record_stage(int i, hipStream_t stream);  // no-op unless sfa_debug_set_stage_events() armed it
 bool stage_events_armed();
 extern void* g_debug_ptr;                       // sfa_debug_set_ptr(): device buffer of the stamped diagnostic bodies
-extern int g_variant[8];                        // sfa_debug_set_variant(): 0 = dK/dV body, 1 = forward, 2 = dQ (A/B builds)
+extern int g_variant[8];                        // sfa_debug_set_variant(): 0 = dK/dV body, 1 = forward, 2 = dQ, 3 = dK/dV workgroup order, 7 = tickets off
+// A/B hook: read by -DSFA_AB development builds only; a release build compiles every such branch away
+#ifdef SFA_AB
 inline int variant(int which) { return __atomic_load_n(&g_variant[which], __ATOMIC_RELAXED); }
+#else
+inline int variant(int) { return 0; }
+#endif
 
 #define SFA_CHECK_ARG(cond, ...)             \
     do {                                     \
@@ -45,11 +50,16 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long
     }
 }
 
-// integer tuning knob from the environment, read ONCE per call site (getenv is not free and not thread-safe against
-// setenv): static const int knob = env_int("SFA_X", default);
+// integer tuning knob: the default in a release build; -DSFA_AB development builds read SFA_<NAME> from the environment,
+// ONCE per call site (getenv is not free and not thread-safe against setenv): static const int knob = env_int("SFA_X", default);
 inline int env_int(const char* name, int dflt) {
+#ifdef SFA_AB
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 inline int launch_status(const char* what) {

@@ -32,7 +32,7 @@ int bwd_mfma(const sfa_tensor* q, const sfa_tensor* k, const sfa_tensor* v, cons
              const sfa_tensor* dv, void* workspace, const Problem& p, unsigned flags, hipStream_t stream,
              bool consts_ready = false);
 bool bwd_mfma_wants_consts();   // the default dK/dV kernels read the row constants from the head of the workspace
-float bwd_mfma_lse_factor(const Problem& p);   // ... whose first row is -LSE * this factor
+float bwd_mfma_lse_factor(const Problem& p, unsigned flags);   // ... whose first row is -LSE * this factor (follows the dK/dV kernel choice)
 
 // sfa_decode.hip
 struct DecodePlan {

@@ -11,6 +11,7 @@ from .verl_patch import patch_verl_with_sink_attention, unpatch_verl
 from .generate_patch import patch_for_generation, unpatch_generation
 from .sp_utils import prepare_sink_kv_for_sp, reduce_sink_kv_grads, SinkAttentionSPWrapper
 from .varlen import sink_flash_attention_varlen
+from ._native import set_backward_options
 
 __version__ = "0.1.0"
 
@@ -29,4 +30,5 @@ __all__ = [
     "reduce_sink_kv_grads",
     "SinkAttentionSPWrapper",
     "sink_flash_attention_varlen",
+    "set_backward_options",
 ]

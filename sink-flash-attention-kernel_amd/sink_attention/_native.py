@@ -19,7 +19,40 @@ LIB_PATH = os.environ.get("SFA_LIB_PATH") or os.path.join(_HERE, "libsfa.so")   
 SFA_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 FLAG_FORCE_GENERIC = 0x1
 FLAG_DECODE_ONE_PASS = 0x4
-ABI_VERSION = 1
+FLAG_BWD_OVERLAP = 0x8        # dQ kernel of a small grid on the library's side stream (include/sfa.h)
+FLAG_BWD_DKDV_ASM = 0x10      # dispatch override: hand-placed dK/dV kernel
+FLAG_BWD_DKDV_WS = 0x20       # dispatch override: wave-specialised compiled dK/dV kernel
+ABI_VERSION = 2
+
+# flags every backward of the ops passes to sfa_bwd / sfa_bwd_varlen (and to the workspace query): the overlap is ON by
+# default here - the C entry points do nothing of the kind unless asked
+_bwd_flags = FLAG_BWD_OVERLAP
+
+
+def set_backward_options(overlap=None, dkdv=None):
+    """Process-wide options of the ops' backward pass.  overlap: True / False - dQ kernel of small grids on the library's
+    side stream (default True).  dkdv: None (the library's rule) / "asm" (hand-placed kernel) / "ws" (wave-specialised
+    compiled kernel): the dispatch override the parity tests use.  Returns the previous (overlap, dkdv)."""
+    global _bwd_flags
+    prev = (bool(_bwd_flags & FLAG_BWD_OVERLAP),
+            "asm" if _bwd_flags & FLAG_BWD_DKDV_ASM else ("ws" if _bwd_flags & FLAG_BWD_DKDV_WS else None))
+    f = _bwd_flags
+    if overlap is not None:
+        f = (f | FLAG_BWD_OVERLAP) if overlap else (f & ~FLAG_BWD_OVERLAP)
+    if dkdv is not None or overlap is None:
+        f &= ~(FLAG_BWD_DKDV_ASM | FLAG_BWD_DKDV_WS)
+        if dkdv == "asm":
+            f |= FLAG_BWD_DKDV_ASM
+        elif dkdv == "ws":
+            f |= FLAG_BWD_DKDV_WS
+        elif dkdv not in (None, "rule"):
+            raise ValueError("dkdv must be None, 'rule', 'asm' or 'ws'")
+    _bwd_flags = f
+    return prev
+
+
+def bwd_flags(flags=0) -> int:
+    return flags | _bwd_flags
 
 
 class SfaTensor(ctypes.Structure):

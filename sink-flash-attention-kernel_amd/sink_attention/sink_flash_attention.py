@@ -83,7 +83,7 @@ class SinkFlashAttentionFunc(torch.autograd.Function):
         dv = mk((B, H_kv, k.shape[2], D), device=q.device, dtype=q.dtype)
         ds_aux = mk((H_q,), device=q.device, dtype=torch.float32) if ctx.use_s_aux else None
         lib = N.lib()
-        flags = ctx.flags
+        flags = N.bwd_flags(ctx.flags)
         ws_bytes = lib.sfa_bwd_workspace_bytes(B, H_q, H_kv, Nq, D, N.SFA_DTYPE[q.dtype], ctx.num_sink,
                                                ctx.window_size, flags)
         ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)

@@ -72,13 +72,14 @@ class SinkFlashAttentionVarlenFunc(torch.autograd.Function):
         dv = alloc((1, H_kv, T, D), device=q.device, dtype=q.dtype)
         ds_aux = torch.empty((H_q,), device=q.device, dtype=torch.float32) if use_s_aux else None
         lib = N.lib()
-        ws_bytes = lib.sfa_bwd_workspace_bytes(1, H_q, H_kv, T, D, N.SFA_DTYPE[q.dtype], num_sink, window_size, 0)
+        flags = N.bwd_flags()
+        ws_bytes = lib.sfa_bwd_workspace_bytes(1, H_q, H_kv, T, D, N.SFA_DTYPE[q.dtype], num_sink, window_size, flags)
         ws = torch.empty((max(int(ws_bytes), 256),), device=q.device, dtype=torch.uint8)
         with torch.cuda.device(q.device):
             st = lib.sfa_bwd_varlen(N.desc(q), N.desc(k), N.desc(v), N.desc(o), N.desc(do), lse.data_ptr(),
                                     s_aux_f.data_ptr() if use_s_aux else None, N.desc(dq), N.desc(dk), N.desc(dv),
                                     ds_aux.data_ptr() if use_s_aux else None, cu_dev.data_ptr(), cu_dev.numel() - 1,
-                                    max_seqlen, ws.data_ptr(), ws.numel(), num_sink, window_size, scale, 0,
+                                    max_seqlen, ws.data_ptr(), ws.numel(), num_sink, window_size, scale, flags,
                                     N.stream_ptr(q.device))
         N.check(st, "sfa_bwd_varlen")
         if use_s_aux and ds_aux.dtype != s_aux_dtype:

@@ -14,15 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_collection_modifyitems(config, items):
-    """GPU runs: keep the hand-placed dK/dV kernel on the small shapes of the parity tests (the library would hand grids
-    smaller than the chip to the compiled kernel; tests/test_gpu_prefill.py::test_small_grids_row_split_or_compiled_dkdv_kernel
-    switches the rule back on for itself)."""
-    if any("gpu" in it.keywords for it in items):
-        try:
-            import torch
-            if torch.cuda.is_available():
-                from sink_attention import _native
-                _native.lib().sfa_debug_set_variant(4, 1)
-        except Exception:      # noqa: BLE001 - no GPU / no library: the GPU tests will say so themselves
-            pass
+import pytest
+
+
+@pytest.fixture(params=["rule", "asm"])
+def dkdv(request):
+    """Backward parity tests run twice: under the library's own dK/dV kernel rule ("rule": what ships) and with the
+    hand-placed kernel forced wherever its body serves the shape ("asm": SFA_FLAG_BWD_DKDV_ASM, so that small test shapes
+    reach it too).  Yields the mode; tests/util.py::dkdv_kernel_name() says which kernel name sfa_last_path() must show."""
+    from sink_attention import set_backward_options
+    prev = set_backward_options(dkdv=request.param)
+    try:
+        yield request.param
+    finally:
+        set_backward_options(overlap=prev[0], dkdv=prev[1] or "rule")

@@ -184,18 +184,3 @@ def test_other_head_dims_in_emulator(D):
         for gen in (DkdvGen, DqGen, FwdGen):
             ok, err = assemble(_prog("bf16", True, gen, D))
             assert ok, err[:2000]
-
-
-def test_fwd_stamped_diagnostic_body_runs_and_agrees():
-    """the s_memtime-stamped build of the forward body (tools/stamps_fwd.py) stores only into its own debug records
-    (one 32-byte record per wave) and computes the same output"""
-    g = torch.Generator().manual_seed(9)
-    q = torch.randn(1, 4, 200, 128, generator=g).bfloat16()
-    k, v = (torch.randn(1, 1, 200, 128, generator=g).bfloat16() for _ in range(2))
-    a = run_fwd(_prog("bf16", True, FwdGen, persist=False), q, k, v, 4, 70, None, "bf16")
-    st = []
-    b = run_fwd(FwdGen("bf16", stamps=True, persist=False).build(), q, k, v, 4, 70, None, "bf16", stats=st, stamped=True)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    rec = st[-1]["dbg"]                       # [workgroup, wave, 8]
-    assert (rec[:, :, 6] > 0).all() and (rec[:, :, 7] == 0).all()
-    assert (rec[:, :, 1] <= rec[:, :, 2]).all() and (rec[:, :, 2] <= rec[:, :, 3]).all() and (rec[:, :, 4] <= rec[:, :, 5]).all()

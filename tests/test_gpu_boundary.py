@@ -151,3 +151,71 @@ def test_ops_run_on_the_current_stream_and_capture_into_a_hip_graph():
     assert torch.equal(out_g, exp) and torch.equal(dec_g, ref_dec)
     assert torch.equal(qs.grad, q2.grad) and torch.equal(ks.grad, k2.grad) and torch.equal(vs.grad, v2.grad)
     assert torch.equal(ss.grad, s2.grad)
+
+
+def test_raw_sfa_bwd_first_call_of_a_thread_under_graph_capture():
+    """include/sfa.h, SFA_FLAG_BWD_OVERLAP: the side stream of the dQ / dK-dV overlap is created at a thread's first
+    overlapped call on a device, and never while the caller's stream is capturing.  A fresh thread whose FIRST sfa_bwd
+    (small grid, overlap requested) runs inside torch.cuda.graph capture must therefore capture a plain single-stream
+    backward; after one uncaptured call of the same thread (which creates the stream) a captured call forks / joins the
+    side stream inside the graph.  All three against the oracle."""
+    import threading
+    from sink_attention import _native as N
+    from sink_attention import sink_flash_attention
+    from util import oracle_bwd, rand, assert_close
+    lib = N.lib()
+    g = torch.Generator().manual_seed(71)
+    B, Hq, Hkv, Nq, D, ns, W = 1, 4, 1, 1024, 128, 4, 300          # 16 dQ workgroups, 4 key blocks: a small grid
+    q, k, v, do = (rand(s, g, torch.bfloat16) for s in ((B, Hq, Nq, D), (B, Hkv, Nq, D), (B, Hkv, Nq, D), (B, Hq, Nq, D)))
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
+    qd, kd, vd, dod = (t.to(DEV) for t in (q, k, v, do))
+    from sink_attention.sink_flash_attention import SinkFlashAttentionFunc
+    # forward through the C ABI to get o and lse
+    o = torch.empty_like(qd)
+    lse = torch.empty(B, Hq, Nq, device=DEV, dtype=torch.float32)
+    scale = D ** -0.5
+    N.check(lib.sfa_fwd(N.desc(qd), N.desc(kd), N.desc(vd), N.desc(o), lse.data_ptr(), None, ns, W, scale, 0,
+                        N.stream_ptr(qd.device)), "sfa_fwd")
+    flags = N.FLAG_BWD_OVERLAP
+    ws_bytes = lib.sfa_bwd_workspace_bytes(B, Hq, Hkv, Nq, D, N.SFA_DTYPE[qd.dtype], ns, W, flags)
+    ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=DEV)
+    grads = [[torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)] for _ in range(3)]
+    torch.cuda.synchronize()
+    paths, errors = [], []
+
+    def bwd(dst):
+        st = lib.sfa_bwd(N.desc(qd), N.desc(kd), N.desc(vd), N.desc(o), N.desc(dod), lse.data_ptr(), None, N.desc(dst[0]),
+                         N.desc(dst[1]), N.desc(dst[2]), None, ws.data_ptr(), ws.numel(), ns, W, scale, flags,
+                         N.stream_ptr(qd.device))
+        N.check(st, "sfa_bwd")
+        paths.append(N.last_path())
+
+    def worker():
+        try:
+            torch.cuda.set_device(qd.device)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=s, capture_error_mode="thread_local"):
+                    bwd(grads[0])                      # first sfa_bwd of this thread: under capture
+                g1.replay()
+                bwd(grads[1])                          # uncaptured: creates the side stream
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=s, capture_error_mode="thread_local"):
+                    bwd(grads[2])                      # captured WITH the fork / join
+                g2.replay()
+            s.synchronize()
+        except Exception as e:      # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    assert "overlap" not in paths[0] and paths[1].endswith("_overlap") and paths[2].endswith("_overlap"), paths
+    for dst in grads:
+        assert_close(dst[0], dq_r, 5e-2, 5e-2, "dq")
+        assert_close(dst[1], dk_r, 1e-1, 5e-2, "dk")
+        assert_close(dst[2], dv_r, 1e-1, 5e-2, "dv")
+    assert all(torch.equal(a, b) for a, b in zip(grads[0], grads[1])) and all(torch.equal(a, b) for a, b in zip(grads[1], grads[2]))

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import golden_util as G
-from util import assert_close, make_qkv, maxdiff, oracle_bwd, oracle_fwd, rand
+from util import dkdv_kernel_name, assert_close, make_qkv, maxdiff, oracle_bwd, oracle_fwd, rand
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,7 @@ def test_forward_correctness(B, Hq, Hkv, N, D, ns, W):
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W", [(1, 4, 4, 128, 64, 4, 32), (1, 4, 2, 128, 64, 4, 64)])  # :201-204
-def test_backward_correctness(B, Hq, Hkv, N, D, ns, W):
+def test_backward_correctness(B, Hq, Hkv, N, D, ns, W, dkdv):
     q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.float32)
     do = rand((B, Hq, N, D), g, torch.float32)
     # oracle on the fp32 values (the reference compares an fp16 kernel with fp32 autograd, :71-96)
@@ -215,12 +215,13 @@ EXT_BWD = [(1, 4, 4, n, 64, 4, 32) for n in (64, 128, 256)] + [
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,N,D,ns,W", EXT_BWD)
-def test_extended_backward(B, Hq, Hkv, N, D, ns, W):
+def test_extended_backward(B, Hq, Hkv, N, D, ns, W, dkdv):
     q, k, v, g = make_qkv(B, Hq, Hkv, N, D, torch.float32)
     do = rand((B, Hq, N, D), g, torch.float32)
     dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
     qt, kt, vt = (t.half().to(DEV).requires_grad_(True) for t in (q, k, v))
     _op()(qt, kt, vt, num_sink=ns, window_size=W).backward(do.half().to(DEV))
+    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W) in _path(), _path()
     assert_close(qt.grad.float(), dq_r, 5e-2, 5e-2, "dq")
     assert_close(kt.grad.float(), dk_r, 5e-2, 5e-2, "dk")
     assert_close(vt.grad.float(), dv_r, 5e-2, 5e-2, "dv")
@@ -238,7 +239,7 @@ def test_forward_long_seq(N):                       # benchmark.py:91-104 -- her
 
 
 @pytest.mark.parametrize("N", [2048, 4096, 8192])
-def test_backward_long_seq(N):                      # benchmark.py:107-119
+def test_backward_long_seq(N, dkdv):                      # benchmark.py:107-119
     q, k, v, _ = make_qkv(1, 4, 4, N, 64, torch.float16)
     q, k, v = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
     _op()(q, k, v, num_sink=4, window_size=4096).sum().backward()
@@ -252,7 +253,7 @@ GOLD = [n for n in G.names("f") if n[:2] in ("f1", "f2", "f3", "f4", "f5")]
 
 @pytest.mark.parametrize("force_generic", [False, True])
 @pytest.mark.parametrize("name", GOLD)
-def test_golden_fwd_bwd(name, force_generic):
+def test_golden_fwd_bwd(name, force_generic, dkdv):
     g = G.load(name)
     m = G.fwd_bwd_meta(g)
     if "fp16" in name:
@@ -286,7 +287,7 @@ def test_golden_fwd_bwd(name, force_generic):
     (1, 8, 2, 700, 128, 4, 128, True),    # several KV tiles, window edges inside tiles
     (1, 4, 4, 513, 64, 70, 100, False),   # sink range spanning more than one tile
 ])
-def test_shapes_fwd_bwd(B, Hq, Hkv, N, D, ns, W, aux, dtype):
+def test_shapes_fwd_bwd(B, Hq, Hkv, N, D, ns, W, aux, dtype, dkdv):
     q, k, v, g = make_qkv(B, Hq, Hkv, N, D, dtype)
     do = rand((B, Hq, N, D), g, dtype)
     sa = rand((Hq,), g, torch.float32, 0.5) if aux else None
@@ -296,6 +297,8 @@ def test_shapes_fwd_bwd(B, Hq, Hkv, N, D, ns, W, aux, dtype):
     sad = sa.to(DEV).requires_grad_(True) if aux else None
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     out.backward(do.to(DEV))
+    want = dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W, dtype=dtype)
+    assert want is None or want in _path(), (want, _path())
     to, tg = {torch.float32: (2e-5, 2e-4), torch.float16: (4e-3, 3e-2), torch.bfloat16: (2e-2, 1.5e-1)}[dtype]
     assert maxdiff(out, o_r) < to, f"o ({_path()})"
     assert maxdiff(qd.grad, dq_r) < tg, "dq"
@@ -318,7 +321,7 @@ def test_strided_bnhd_inputs_and_output():
     assert maxdiff(out, ref) < 2e-2
 
 
-def test_deterministic_bitwise():
+def test_deterministic_bitwise(dkdv):
     q, k, v, g = make_qkv(2, 8, 2, 384, 128, torch.bfloat16)
     do = rand((2, 8, 384, 128), g, torch.bfloat16).to(DEV)
     sa = rand((8,), g, torch.float32).to(DEV)
@@ -346,7 +349,7 @@ def test_mfma_path_is_used_for_headline_shapes():
 
 
 @pytest.mark.parametrize("B,Hkv", [(2, 4), (4, 4), (2, 8), (3, 8)])
-def test_backward_with_many_kv_groups(B, Hkv):
+def test_backward_with_many_kv_groups(B, Hkv, dkdv):
     """B * H_kv = 8, 16 (and 24: three groups per XCD share): the dK/dV kernels order their workgroups per XCD (heavy
     sink blocks first) with index arithmetic that only engages when the (batch, KV head) count is a multiple of 8 -
     the branch the C3 bench runs (B * H_kv = 32).  Several key blocks, sinks, a window shorter than N, GQA."""
@@ -358,7 +361,7 @@ def test_backward_with_many_kv_groups(B, Hkv):
     sad = sa.to(DEV).requires_grad_(True)
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     out.backward(do.to(DEV))
-    assert "mfma" in _path(), _path()
+    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W) in _path(), _path()      # (dense batch: the hand-placed kernel + row split either way)
     o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
     dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
     assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "fwd")
@@ -369,7 +372,7 @@ def test_backward_with_many_kv_groups(B, Hkv):
 
 
 @pytest.mark.parametrize("D,dtype", [(64, torch.bfloat16), (80, torch.bfloat16), (96, torch.float16), (64, torch.float16)])
-def test_hand_placed_kernels_other_head_dims(D, dtype):
+def test_hand_placed_kernels_other_head_dims(D, dtype, dkdv):
     """head dims 64 / 80 / 96 with a window long enough for the hand-placed kernels (the compiled ones keep the short
     windows): GQA, sinks, s_aux, ragged N, strided BNHD inputs, against the oracle"""
     B, Hq, Hkv, N, ns, W = 2, 8, 2, 777, 4, 400
@@ -450,7 +453,7 @@ def test_head_dim_256_backward_larger_shapes():
     (2, 2, 1, 900, 1200, 80, 130, 64, torch.float16),       # the same with N_q < N_kv and sinks beyond a 128-key block
     (1, 2, 1, 20000, 20000, 128, 4, 32, torch.bfloat16),    # more chunks than the cap of 64 (banded oracle)
 ])
-def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype):
+def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype, dkdv):
     """key block 0 (the sink keys see every row) is swept by several workgroups whose partial dK / dV are added up:
     against the oracle, and bitwise deterministic across runs"""
     from sink_attention import _native
@@ -464,7 +467,7 @@ def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype):
         sad = sa.to(DEV).requires_grad_(True)
         out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
         out.backward(do.to(DEV))
-        assert ("dkdvasm4x64" if (D == 128 or W > 256) else "dkdvws8") in _path(), _path()
+        assert dkdv_kernel_name(dkdv, B, Hkv, N, Nk, D, W) in _path(), _path()
         grads.append((qd.grad.clone(), kd.grad.clone(), vd.grad.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*grads))
     dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W, sa)
@@ -478,14 +481,16 @@ def test_small_grids_row_split_or_compiled_dkdv_kernel():
     cuts EVERY block's sweep into chunks (row split, partial dK / dV added up in a fixed order); with N_q < N_kv the
     workspace query cannot size the partials and the compiled kernel (128-key blocks: twice the workgroups) takes over.
     Both against the oracle, with the library's own rule (the other GPU tests force the hand-placed kernel)."""
-    from sink_attention import _native
-    lib = _native.lib()
+    from sink_attention import set_backward_options
+    prev = set_backward_options(dkdv="rule")
     try:
-        lib.sfa_debug_set_variant(4, 0)
         for (B, Hq, Hkv, N, Nk, D, ns, W, want) in ((1, 4, 1, 2048, 2048, 128, 4, 512, "dkdvasm4x64"),      # one KV head: 8 blocks
                                                     (1, 4, 1, 1500, 1500, 64, 300, 700, "dkdvasm4x64"),     # sinks over two blocks
                                                     (2, 4, 2, 1000, 1000, 128, 0, 1000, "dkdvasm4x64"),     # causal, no sinks
-                                                    (1, 8, 2, 1024, 1200, 128, 4, 4096, "dkdvws8")):        # N_q < N_kv
+                                                    (1, 8, 2, 1024, 1200, 128, 4, 4096, "dkdvws8"),         # N_q < N_kv
+                                                    (2, 4, 1, 300, 1500, 128, 4, 700, "dkdvws8"),           # N_q << N_kv, window edge inside
+                                                    (1, 8, 8, 512, 700, 96, 0, 400, "dkdvws8"),             # MHA, no sinks, head dim 96
+                                                    (1, 4, 2, 77, 2000, 64, 130, 900, "dkdvws8")):          # ragged rows, sinks over three 64-key tiles
             q, do = rand((B, Hq, N, D), torch.Generator().manual_seed(N), torch.bfloat16), None
             g = torch.Generator().manual_seed(N + 1)
             do = rand((B, Hq, N, D), g, torch.bfloat16)
@@ -502,10 +507,10 @@ def test_small_grids_row_split_or_compiled_dkdv_kernel():
             assert_close(grads[0][1], dk_r, 1e-1, 5e-2, "dk")
             assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
     finally:
-        lib.sfa_debug_set_variant(4, 1)
+        set_backward_options(overlap=prev[0], dkdv=prev[1] or "rule")
 
 
-def test_baseline_c4_full_shape():
+def test_baseline_c4_full_shape(dkdv):
     """BASELINE.json configs[3] at its REAL shape: gpt-oss-20b sliding layer, bf16, H_q=64, H_kv=8, D=80, N=8192,
     window=128, s_aux, fwd+bwd including ds_aux, against the banded oracle (cheap at W=128)."""
     B, Hq, Hkv, N, D, ns, W = 1, 64, 8, 8192, 80, 0, 128
@@ -518,7 +523,7 @@ def test_baseline_c4_full_shape():
     sad = sa.to(DEV).requires_grad_(True)
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     out.backward(do.to(DEV))
-    assert "mfma" in _path(), _path()
+    assert "dkdvws8" in _path(), _path()            # D = 80, W = 128: the compiled short-window kernels in both modes
     assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "C4 fwd")
     assert_close(qd.grad, dq_r, 5e-2, 5e-2, "C4 dq")
     assert_close(kd.grad, dk_r, 1e-1, 5e-2, "C4 dk")
@@ -527,7 +532,7 @@ def test_baseline_c4_full_shape():
 
 
 @pytest.mark.parametrize("cfg", ["C2", "C3slice", "C4slice"])
-def test_baseline_config_shapes_against_banded_oracle(cfg):
+def test_baseline_config_shapes_against_banded_oracle(cfg, dkdv):
     """BASELINE.json configs at full N on a slice of (batch, heads) small enough for the CPU oracle."""
     if cfg == "C2":      # fwd MHA bf16 N=4096 D=128 ns=4 W=1024
         B, Hq, Hkv, N, D, ns, W, aux = 1, 2, 2, 4096, 128, 4, 1024, False

@@ -5,14 +5,14 @@ import pytest
 import torch
 
 from oracle import sink_oracle as O
-from util import maxdiff, rand
+from util import dkdv_kernel_name, maxdiff, rand
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
 @pytest.mark.parametrize("P,n,ns,W", [(4, 64, 4, 100), (2, 96, 0, 50), (3, 40, 6, 200)])
-def test_sp_rank_local_attention_matches_full_sequence(P, n, ns, W):
+def test_sp_rank_local_attention_matches_full_sequence(P, n, ns, W, dkdv):
     from sink_attention import sink_flash_attention
     from sink_attention.sp_utils import sp_extended_kv, sp_local_attention
     g = torch.Generator().manual_seed(41)
@@ -80,7 +80,7 @@ def test_generation_forward_prefill_then_decode_with_cache():
     (8, 1, 80, 333, 400, 130, 64),       # sinks longer than a key block, MQA, D=80
     (4, 2, 96, 1, 257, 2, 10000),        # a single query row, window longer than everything
     (4, 2, 128, 1024, 1100, 4, 512)])    # many query tiles
-def test_fewer_queries_than_keys_fwd_bwd(dtype, Hq, Hkv, D, Nq, Nk, ns, W):
+def test_fewer_queries_than_keys_fwd_bwd(dtype, Hq, Hkv, D, Nq, Nk, ns, W, dkdv):
     """N_q < N_kv on the MFMA kernels (queries = the last N_q key positions) against the oracle and against the same
     problem padded with zero queries."""
     from sink_attention import _native
@@ -95,6 +95,8 @@ def test_fewer_queries_than_keys_fwd_bwd(dtype, Hq, Hkv, D, Nq, Nk, ns, W):
     out = _sink_flash_attention_ex(qd, kd, vd, ns, W, s_aux=sad)
     assert out.shape == (B, Hq, Nq, D) and "mfma" in _native.last_path()
     out.backward(do.to(DEV))
+    want = dkdv_kernel_name(dkdv, B, Hkv, Nq, Nk, D, W)
+    assert want in _native.last_path(), (want, _native.last_path())
     o_r, _ = O.sink_attention_dense(q, k, v, ns, W, sa)
     dq_r, dk_r, dv_r, dsa_r = O.sink_attention_bwd_dense(q, k, v, do, ns, W, sa)
     to, tg = (1e-2, 5e-2) if dtype == torch.float16 else (2e-2, 1.5e-1)

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from oracle import sink_oracle as O
-from util import maxdiff, rand
+from util import dkdv_kernel_name, maxdiff, rand
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -25,7 +25,7 @@ def _per_seq_oracle(q, k, v, do, cu, ns, W, sa):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_varlen_fwd_bwd_matches_per_sequence_oracle(dtype):
+def test_varlen_fwd_bwd_matches_per_sequence_oracle(dtype, dkdv):
     from sink_attention.varlen import sink_flash_attention_varlen
     g = torch.Generator().manual_seed(31)
     Hq, Hkv, D, ns, W = 8, 2, 128, 2, 40
@@ -51,8 +51,11 @@ def test_varlen_fwd_bwd_matches_per_sequence_oracle(dtype):
     (8, 1, 80, 130, 50, [0, 129, 700]),                          # MQA, D=80, sinks longer than a key block
     (4, 2, 96, 2, 100000, [0, 257, 640]),                        # window larger than every sequence
     (4, 1, 96, 0, 4096, [0, 200, 264, 265]),                     # pack longer than 256 rows, every sequence shorter: the
-    (1, 1, 80, 130, 300, [0, 200, 400])])                        # row constants must follow the LAUNCH's kernel choice
-def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu):
+    (1, 1, 80, 130, 300, [0, 200, 400]),                         # row constants must follow the LAUNCH's kernel choice
+    (8, 2, 128, 4, 300, [0, 1100, 1101, 2300, 4400]),            # D = 128, W > 256, sinks, SMALL grid (5 blocks x 2 KV heads x 4
+                                                                 # sequences < CUs): the rule takes the compiled kernel, no sink split
+    (16, 16, 128, 4, 600, [0, 4500, 9000])])                     # ... and a pack whose grid fills the chip: hand-placed under the rule too
+def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu, dkdv):
     """The packed kernels (cu_seqlens inside the grid) against the per-sequence oracle, forward and backward, and
     against the sequence-by-sequence path of the same library."""
     from sink_attention import _native
@@ -69,7 +72,9 @@ def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu):
     out = sink_flash_attention_varlen(qd, kd, vd, cu, num_sink=ns, window_size=W, s_aux=sad)
     assert _native.last_path().startswith("fwd_mfma")
     out.backward(do.to(DEV))
-    assert "dkdvws8" in _native.last_path() or "dkdvasm4x64" in _native.last_path()
+    longest = max(b - a for a, b in zip(cu[:-1], cu[1:]))
+    want = dkdv_kernel_name(dkdv, len(cu) - 1, Hkv, longest, longest, D, W, packed=True)
+    assert want in _native.last_path(), (want, _native.last_path())
     o_r, dq_r, dk_r, dv_r, dsa_r = _per_seq_oracle(q, k, v, do, cu, ns, W, sa)
     assert maxdiff(out, o_r) < 2e-2
     assert maxdiff(qd.grad, dq_r) < 1.5e-1 and maxdiff(kd.grad, dk_r) < 1.5e-1 and maxdiff(vd.grad, dv_r) < 1.5e-1

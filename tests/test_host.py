@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
             "sfa_abi_version", "sfa_last_error", "sfa_last_path"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.sfa_abi_version() == 1
+    assert lib.sfa_abi_version() == _native.ABI_VERSION == 2
 
 
 def test_descriptor_matches_header_layout():
@@ -215,3 +215,25 @@ def test_hf_option_binding():
     params = list(inspect.signature(fa._flash_attention_forward).parameters)
     tail = [p for p in params[5:] if p in H.OPTIONAL_ORDER]
     assert tail == [p for p in H.OPTIONAL_ORDER if p in tail]
+
+
+def test_backward_options_map_to_flags():
+    """sink_attention.set_backward_options: the overlap flag is the ops' default (the C entry points create nothing unless
+    asked), the dK/dV dispatch overrides are exclusive, and the previous setting comes back for restoring"""
+    from sink_attention import _native, set_backward_options
+    assert _native.bwd_flags() == _native.FLAG_BWD_OVERLAP
+    prev = set_backward_options(dkdv="asm")
+    assert prev == (True, None) and _native.bwd_flags() == _native.FLAG_BWD_OVERLAP | _native.FLAG_BWD_DKDV_ASM
+    assert set_backward_options(overlap=False, dkdv="ws") == (True, "asm")
+    assert _native.bwd_flags() == _native.FLAG_BWD_DKDV_WS and _native.bwd_flags(1) == _native.FLAG_BWD_DKDV_WS | 1
+    set_backward_options(overlap=True, dkdv="rule")
+    assert _native.bwd_flags() == _native.FLAG_BWD_OVERLAP
+    # flag values of include/sfa.h
+    hdr = open(os.path.join(ROOT, "include", "sfa.h")).read()
+    for name, val in (("SFA_FLAG_BWD_OVERLAP", _native.FLAG_BWD_OVERLAP), ("SFA_FLAG_BWD_DKDV_ASM", _native.FLAG_BWD_DKDV_ASM),
+                      ("SFA_FLAG_BWD_DKDV_WS", _native.FLAG_BWD_DKDV_WS)):
+        assert re.search(r"#define %s 0x%xu" % (name, val), hdr), name
+    # the workspace query takes the override bits (the partial-sum area follows the kernel choice)
+    lib = _native.lib()
+    for f in (0, _native.FLAG_BWD_DKDV_ASM, _native.FLAG_BWD_DKDV_WS, _native.FLAG_BWD_OVERLAP):
+        assert lib.sfa_bwd_workspace_bytes(1, 8, 2, 4096, 128, 2, 4, 1024, f) >= 8 * 4096 * 4

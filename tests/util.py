@@ -49,3 +49,23 @@ def assert_close(actual, expected, atol, rtol, what=""):
     bad = err > tol
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance "
                            f"(atol={atol}, rtol={rtol}); max abs err {err.max().item():.3e}")
+
+
+def dkdv_kernel_name(mode, B, Hkv, Nq, Nk, D, window, packed=False, dtype=torch.bfloat16):
+    """Name of the dK/dV kernel sfa_bwd must dispatch to, as it appears in sfa_last_path(): restates dkdv_asm() of
+    csrc/sfa_bwd_mfma.hip.  mode: "rule" (the library's rule) / "asm" / "ws" (the per-call overrides).  None where the
+    choice does not exist (fp32, head dims without a hand-placed body).  Packed batches: B = sequences, Nq = Nk = the
+    longest one (the launch problem of sfa_bwd_varlen)."""
+    if dtype == torch.float32 or D not in (64, 80, 96, 128):
+        return None
+    W = min(max(window, 0), Nk)
+    if not (D == 128 or W > 256):          # short windows below head dim 128: compiled kernels only
+        return "dkdvws8"
+    if mode == "asm":
+        return "dkdvasm4x64"
+    if mode == "ws":
+        return "dkdvws8"
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    dense = (not packed) and Nq == Nk      # row split available: the hand-placed kernel fills the chip whatever the grid
+    fills = -(-Nk // 256) * Hkv * B >= n_cu
+    return "dkdvasm4x64" if (dense or fills) else "dkdvws8"

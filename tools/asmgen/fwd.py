@@ -51,12 +51,13 @@ PARAMS = [
 class FwdGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", stamps=False, kpre=True, kpre_dl=300, persist=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", kpre=True, kpre_dl=300, persist=True, trans_sched=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         self.persist = persist
+        self.trans_sched = trans_sched        # item transition placed by the gap scheduler (the pipeline fill's MFMAs beside the store tail)
         if persist:
-            assert lsum == "mfma" and kpre and not stamps
+            assert lsum == "mfma" and kpre
         if sfirst is None:
             sfirst = 44 if persist else 56
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
@@ -111,10 +112,6 @@ class FwdGen(WorkList):
         self.s_koff, self.s_voff = sa("s_koff"), sa("s_voff")
         self.s_wofs, self.s_cls = sa("s_wofs"), sa("s_cls")
         self.s_tmp = [sa("s_tmp%d" % i) for i in range(5)]
-        self.stamps = stamps              # diagnostic build (tools/stamps_fwd.py): s_memtime at the ends of prologue / loop / epilogue
-        if stamps:
-            self.s_tt = sa("s_tt", 2, 2)
-            self.s_T = [sa("s_T%d" % i) for i in range(5)]
         if persist:
             self.wl_alloc(sa)
         self.r_nt = self.s_nt if persist else P("nt")
@@ -125,13 +122,7 @@ class FwdGen(WorkList):
     def params(self):
         if self.persist:
             return list(PARAMS_PK)
-        return list(PARAMS) + (["dbg_lo", "dbg_hi", "bid", "t_entry"] if self.stamps else [])
-
-    def emit_stamp(self, p: Prog, k: int):
-        if self.stamps:
-            p.add(Instr("s_memtime", [self.s_tt], [], kind="fence"))
-            p.s_waitcnt(lgkmcnt=0)
-            p.s_mov(self.s_T[k], self.s_tt[0])
+        return list(PARAMS)
 
     def pool(self):
         r = self.POOL[self.pool_next % len(self.POOL)]
@@ -331,7 +322,6 @@ class FwdGen(WorkList):
         t0, t1, t2, t3 = self.tmp[:4]
         st = self.s_tmp
         lane, wv = self.lane, self.s_wave
-        self.emit_stamp(p, 0)
         p.v_and(lane, 63, PV("tid"))
         p.v_lshrrev(t0, 6, PV("tid"))
         p.v_readfirstlane(wv, t0)
@@ -469,7 +459,6 @@ class FwdGen(WorkList):
             p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
             p.v_xor(self.a_k_o, 32, self.a_k_e)
             self.emit_k_prefetch(p, self.a_k_e, self.a_k_o)
-        self.emit_stamp(p, 1)
         return p
 
     # ------------------------------------------------------------------ loop head
@@ -569,7 +558,6 @@ class FwdGen(WorkList):
         t0, t1, t2, t3, t4, t5 = self.tmp
         st = self.s_tmp
         p.label("L_done%=")
-        self.emit_stamp(p, 2)
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
         # O[row, d] = O^T[d, row] / l (l = 0 -> 1), LSE = ln2 (m + log2 l)
         p.s_mul_i32(st[1], self.s_hh, P("o_hs"))
@@ -639,26 +627,7 @@ class FwdGen(WorkList):
         p.v_add_u32(t5, 128, t1)
         p.buffer_store(lg[0], t1, self.d_x, 0)
         p.buffer_store(lg[1], t5, self.d_x, 0)
-        self.emit_stamp(p, 3)
         p.s_waitcnt(vmcnt=0)
-        if self.stamps:
-            # lane 0 of every wave: [t_entry, asm start, loop start, loop end, stores issued, stores done, tiles, 0] at
-            # dbg[(4 bid + wave) * 32 bytes] (other lanes out of range)
-            self.emit_stamp(p, 4)
-            p.s_mov(self.d_x[0], P("dbg_lo"))
-            p.s_mov(self.d_x[1], P("dbg_hi"))
-            p.s_mov(self.d_x[3], 0x00020000)
-            p.s_lshl_b32(st[0], P("bid"), 2)
-            p.s_add_u32(st[0], st[0], self.s_wave)
-            p.s_lshl_b32(st[0], st[0], 5)
-            p.s_add_u32(self.d_x[2], st[0], 32, note="records end behind this wave's 32 bytes")
-            p.v_mov(t0, st[0])
-            p.v_cmp("eq_u32", 0, self.lane)
-            p.v_cndmask(t0, self.v_oob, t0)
-            for k, src in enumerate([P("t_entry")] + self.s_T + [P("nt")]):
-                p.v_mov(t1, src)
-                p.buffer_store(t1, t0, self.d_x, 0, offset=4 * k)
-            p.s_waitcnt(vmcnt=0)
         return p
 
 
@@ -940,7 +909,8 @@ class FwdGen(WorkList):
         self.emit_item_begin(p)
         self.emit_stores(p)
         self.emit_item_init(p)
-        items += fix_hazards(insert_waits(p.items, strict_tail=True))
+        blk = schedule(p.items) if (self.trans_sched and self.do_sched) else p.items
+        items += fix_hazards(insert_waits(blk, strict_tail=True))
         items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
         p = Prog()
         p.label("L_last%=")

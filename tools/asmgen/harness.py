@@ -230,7 +230,7 @@ def run_dq(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=
 
 
 # ------------------------------------------------------------------------------------------------ forward kernel
-def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=True, stats=None, stamped=False, persist=False, n_wg=3):
+def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=True, stats=None, persist=False, n_wg=3):
     """q [B, Hq, N, D]; k, v [B, Hkv, Nk, D]; s_aux [Hq] or None.  Returns o [B, Hq, N, D] float32, lse [B, Hq, N].
     persist: the work-list form of the body (n_wg persistent workgroups share the items)."""
     from . import fwd as KF
@@ -246,8 +246,6 @@ def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=Tru
     alse = mem.alloc_zero(B * Hq * N * 4)
     BM = 64 * (4 // hpw)
     nqt = (N + BM - 1) // BM
-    dbg = mem.alloc_zero(B * Hkv * (g // hpw) * nqt * 128) if stamped else None     # stamped diagnostic body: 32 bytes per wave
-    bid = 0
     if persist:
         rng_q = ((N - 1) * D + D) * 2
         rng_k = ((Nk - 1) * D + D) * 2
@@ -300,15 +298,10 @@ def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=Tru
                         tw_off=bp["tw_off"], hpw_log2={1: 0, 2: 1, 4: 2}[hpw], c_log2=f32_bits(scale * log2e),
                         ln2=f32_bits(math.log(2.0)))
                     assert set(params) == set(KF.PARAMS), set(params) ^ set(KF.PARAMS)
-                    if dbg is not None:
-                        params.update(dbg_lo=dbg & 0xFFFFFFFF, dbg_hi=dbg >> 32, bid=bid, t_entry=0)
-                    bid += 1
                     wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
                     wg.run()
                     if stats is not None:
                         stats.append({"block": (b, hk, hg, qt), "nt": bp["nt"], "icount": [w.icount for w in wg.waves]})
-    if stats is not None and dbg is not None:
-        stats.append({"dbg": mem.read(dbg).view(np.uint32).reshape(-1, 4, 8).copy()})
     raw = mem.read(ao).view(np.uint16).reshape(B, Hq, N, D)
     t = torch.from_numpy(raw.view(np.int16).copy())
     o = t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()

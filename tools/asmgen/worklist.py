@@ -13,6 +13,10 @@ over the list:
     finished item's epilogue runs.  What used to be ~10 000 cycles of exposed prologue latency per workgroup (two
     dependent memory round trips) is paid once per CU instead of once per item.
 
+Measured and left out (profiles/r03_ab_l2pf.log): pulling the next item's Q / dO rows into the L2 a few iterations early
+(one dword per 128-byte line by LDS-DMA into a scratch area) - the fragment loads of an item are bound by the CU's
+address / tag path (32 cache lines per instruction), not by where the lines come from: forward unchanged, dQ 0.9 % slower.
+
 Descriptor fields are read with uniform-address ds_read_b128 (every lane the same address: a broadcast) into scratch
 VGPRs and moved to SGPRs with v_readfirstlane.
 """
