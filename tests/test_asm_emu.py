@@ -59,6 +59,21 @@ def test_dkdv_body_in_emulator_matches_oracle(B, Hq, Hkv, N, Nk, ns, W, dtype):
         assert err.max().item() < 4e-2, (name, err.max().item())
 
 
+def test_dkdv_f32_partials_of_a_split_sweep():
+    """the second epilogue (split sweeps): the f32 partial dK / dV of a block's first rows is what the 16-bit output rounds
+    (same accumulators, no rounding), rows beyond fall outside the descriptor and stay untouched"""
+    q, k, v, do, lse, delta, dk, dv = _case(1, 2, 1, 96, 290, 4, 70, "bf16", seed=5)
+    rows = 40
+    dk_e, dv_e, pk, pv = run_dkdv(_prog("bf16", True), q, k, v, do, lse, delta, 4, 70, "bf16", part_rows=rows)
+    for kb in range(2):
+        n = min(rows, 290 - 256 * kb)
+        for part, out, ref in ((pk, dk_e, dk), (pv, dv_e, dv)):
+            sl = slice(256 * kb, 256 * kb + n)
+            assert torch.equal(part[0, 0, kb, :n].bfloat16().float(), out[0, 0, sl])          # the output IS the rounded partial
+            assert (part[0, 0, kb, :n].double() - ref[0, 0, sl]).abs().max().item() < 2e-2
+            assert (part[0, 0, kb, n:] == 0).all()
+
+
 def test_scheduled_body_equals_program_order_bitwise():
     q, k, v, do, lse, delta, _, _ = _case(1, 2, 1, 96, 290, 4, 70, "bf16", seed=5)
     a = run_dkdv(_prog("bf16", False), q, k, v, do, lse, delta, 4, 70, "bf16")

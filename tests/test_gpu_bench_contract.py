@@ -48,5 +48,5 @@ def test_bench_json_contract(tmp_path):
     dq_r, dk_r, dv_r, _ = oracle_bwd(t["q"], t["k"], t["v"], t["do"], t["ns"], t["W"], banded=True)
     assert_close(t["o"], o_r.bfloat16(), 2e-2, 2e-2, "bench fwd")
     assert_close(t["dq"], dq_r, 5e-2, 5e-2, "bench dq")
-    assert_close(t["dk"], dk_r, 1e-1, 5e-2, "bench dk")
-    assert_close(t["dv"], dv_r, 1e-1, 5e-2, "bench dv")
+    assert_close(t["dk"], dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "bench dk")
+    assert_close(t["dv"], dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "bench dv")

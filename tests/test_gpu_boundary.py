@@ -216,6 +216,6 @@ def test_raw_sfa_bwd_first_call_of_a_thread_under_graph_capture():
     assert "overlap" not in paths[0] and paths[1].endswith("_overlap") and paths[2].endswith("_overlap"), paths
     for dst in grads:
         assert_close(dst[0], dq_r, 5e-2, 5e-2, "dq")
-        assert_close(dst[1], dk_r, 1e-1, 5e-2, "dk")
-        assert_close(dst[2], dv_r, 1e-1, 5e-2, "dv")
+        assert_close(dst[1], dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+        assert_close(dst[2], dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
     assert all(torch.equal(a, b) for a, b in zip(grads[0], grads[1])) and all(torch.equal(a, b) for a, b in zip(grads[1], grads[2]))

@@ -366,8 +366,8 @@ def test_backward_with_many_kv_groups(B, Hkv, dkdv):
     dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
     assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "fwd")
     assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
-    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
-    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+    assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+    assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
 
@@ -392,8 +392,8 @@ def test_hand_placed_kernels_other_head_dims(D, dtype, dkdv):
     to = 2e-2 if dtype == torch.bfloat16 else 1e-2
     assert_close(out, o_r, to, to, "fwd")
     assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
-    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
-    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+    assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+    assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
 
@@ -419,8 +419,8 @@ def test_mfma_kernels_head_dims_32_and_256(D, dtype, W):
     to = 2e-2 if dtype == torch.bfloat16 else 1e-2
     assert_close(out, o_r, to, to, "fwd")
     assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
-    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
-    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+    assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+    assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
 
@@ -440,8 +440,8 @@ def test_head_dim_256_backward_larger_shapes():
         dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
         assert_close(out, o_r, 2e-2, 2e-2, "fwd")
         assert_close(qd.grad, dq_r, 5e-2, 5e-2, "dq")
-        assert_close(kd.grad, dk_r, 1e-1, 5e-2, "dk")
-        assert_close(vd.grad, dv_r, 1e-1, 5e-2, "dv")
+        assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+        assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,N,Nk,D,ns,W,dtype", [
@@ -472,8 +472,8 @@ def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype, dkdv):
     assert all(torch.equal(a, b) for a, b in zip(*grads))
     dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W, sa)
     assert_close(grads[0][0], dq_r, 5e-2, 5e-2, "dq")
-    assert_close(grads[0][1], dk_r, 1e-1, 5e-2, "dk")
-    assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
+    assert_close(grads[0][1], dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+    assert_close(grads[0][2], dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
 
 
 def test_small_grids_row_split_or_compiled_dkdv_kernel():
@@ -504,8 +504,8 @@ def test_small_grids_row_split_or_compiled_dkdv_kernel():
             assert all(torch.equal(a, b) for a, b in zip(*grads))          # deterministic
             dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
             assert_close(grads[0][0], dq_r, 5e-2, 5e-2, "dq")
-            assert_close(grads[0][1], dk_r, 1e-1, 5e-2, "dk")
-            assert_close(grads[0][2], dv_r, 1e-1, 5e-2, "dv")
+            assert_close(grads[0][1], dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "dk")
+            assert_close(grads[0][2], dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "dv")
     finally:
         set_backward_options(overlap=prev[0], dkdv=prev[1] or "rule")
 
@@ -526,8 +526,8 @@ def test_baseline_c4_full_shape(dkdv):
     assert "dkdvws8" in _path(), _path()            # D = 80, W = 128: the compiled short-window kernels in both modes
     assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "C4 fwd")
     assert_close(qd.grad, dq_r, 5e-2, 5e-2, "C4 dq")
-    assert_close(kd.grad, dk_r, 1e-1, 5e-2, "C4 dk")
-    assert_close(vd.grad, dv_r, 1e-1, 5e-2, "C4 dv")
+    assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "C4 dk")
+    assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, "C4 dv")
     assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
 
@@ -552,8 +552,8 @@ def test_baseline_config_shapes_against_banded_oracle(cfg, dkdv):
         dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa, banded=True)
         out.backward(do.to(DEV))
         assert_close(qd.grad, dq_r, 5e-2, 5e-2, cfg + " dq")
-        assert_close(kd.grad, dk_r, 1e-1, 5e-2, cfg + " dk")
-        assert_close(vd.grad, dv_r, 1e-1, 5e-2, cfg + " dv")
+        assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, cfg + " dk")
+        assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, cfg + " dv")
         if aux:
             assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
 
@@ -587,3 +587,24 @@ def test_very_long_sequence_and_chunked_tail():
         assert maxdiff(out[0, 1, r0:r0 + 512], o_r) < 2e-2
     tail = _sink_flash_attention_ex(qd.detach()[:, :, N - 8192:], kd.detach(), vd.detach(), ns, W, s_aux=sad.detach())
     assert torch.equal(tail, out.detach()[:, :, N - 8192:])
+
+
+def test_row_split_partials_are_f32_one_rounding():
+    """Small grids: every key block's sweep is cut into chunks whose partial dK / dV are f32 and rounded once
+    (bwd_part_reduce_kernel), so the split result carries no more rounding than the unsplit kernel's.  B = 1, H = 4 / 1,
+    N = 8192, D = 128 (a tensor-parallel shard: 32 key blocks on 256 CUs, row split active) against the SAME problem as
+    batch 0 of a 16-fold batch (512 workgroups: no row split): max |dK - oracle| and max |dV - oracle| of the split run
+    within 1.25 x the unsplit run's."""
+    Hq, Hkv, N, D, ns, W = 4, 1, 8192, 128, 4, 4096
+    q, k, v, g = make_qkv(1, Hq, Hkv, N, D, torch.bfloat16, seed=23)
+    do = rand((1, Hq, N, D), g, torch.bfloat16)
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W, banded=True)
+    res = {}
+    for B in (1, 16):
+        qd, kd, vd = (t.expand(B, -1, -1, -1).contiguous().to(DEV).requires_grad_(True) for t in (q, k, v))
+        _op()(qd, kd, vd, num_sink=ns, window_size=W).backward(do.expand(B, -1, -1, -1).contiguous().to(DEV))
+        assert ("dkdvasm4x64rs" in _path()) == (B == 1), _path()
+        res[B] = (maxdiff(kd.grad[:1], dk_r), maxdiff(vd.grad[:1], dv_r), maxdiff(qd.grad[:1], dq_r))
+    assert res[1][0] <= 1.25 * res[16][0] and res[1][1] <= 1.25 * res[16][1], res
+    assert res[1][2] == res[16][2], res                     # dQ: the same kernel either way
+    assert res[1][0] < 5e-2 * max(1.0, dk_r.abs().max().item()) and res[1][1] < 5e-2 * max(1.0, dv_r.abs().max().item()), res

@@ -43,6 +43,7 @@ PARAMS = [
     "q_sn", "do_sn", "k_sn", "v_sn", "dk_sn", "dv_sn",          # row strides, bytes
     "q_hs", "do_hs", "c_hs",                                    # head strides, bytes
     "nq", "g", "q_row0", "kb0", "pos0", "W", "ns", "nrows", "cdelta", "c_log2", "scale",
+    "pk_lo", "pk_hi", "pv_lo", "pv_hi", "p_rng",               # f32 partial dK / dV of a split sweep (p_rng = 0: none)
 ]
 # q_*/do_*/c_* bases point at (first head of the group, the sequence's first row); q_row0 = first row of the first slice
 # the block sweeps; kb0 = first key of the block; pos0 = position of query row 0 among the keys (N_kv - N_q);
@@ -680,6 +681,35 @@ class DkdvGen:
                         p.v_permlane32_swap(X[0], X[2])
                         p.v_permlane32_swap(X[1], X[3])
                         p.buffer_store(X[0:4], self.vo_k[kbi], self.d_x, 0, offset=64 * db + 32 * gp)
+        # ---- split sweeps (sink split / row split, csrc/sfa_bwd_mfma.hip): this chunk's dK / dV in f32, [key][D] rows of
+        # 4 D bytes at p?_lo (moved back by the block's first key: the key index is absolute); bwd_part_reduce_kernel adds the
+        # chunks up and rounds ONCE.  The accumulator layout gives every lane four consecutive columns per register quad:
+        # registers 4 g .. 4 g + 3 of block (db, kbi) = columns 32 db + 8 g + 4 h ... + 3 of the lane's key.
+        p.s_cmp("eq_u32", P("p_rng"), 0)
+        p.s_cbranch("scc1", "L_nopart%=")
+        p.v_mul_u32_u24(self.vo_k[0], 4 * self.D, t2)
+        p.v_add_u32(self.vo_k[0], self.vo_k[0], t3)                         # + 16 h bytes (4 f32)
+        p.v_add_u32(self.vo_k[1], 32 * 4 * self.D, self.vo_k[0])
+        for which, acc in (("pk", self.DKA), ("pv", self.DV)):
+            p.s_mov(self.d_x[0], P(which + "_lo"))
+            p.s_mov(self.d_x[1], P(which + "_hi"))
+            p.s_mov(self.d_x[2], P("p_rng"))
+            p.s_mov(self.d_x[3], 0x00020000)
+            n = 0
+            for kbi in range(2):
+                for db in range(self.DB):
+                    for g4 in range(4):
+                        if 32 * db + 8 * g4 >= self.D:
+                            continue                                        # padding columns of the last block
+                        X = self.POOL[n % 8]
+                        n += 1
+                        for e in range(4):
+                            p.v_accvgpr_read(X[e], acc[db][kbi][4 * g4 + e])
+                        if which == "pk":
+                            for e in range(4):
+                                p.v_mul_f32(X[e], P("scale"), X[e])
+                        p.buffer_store(X[0:4], self.vo_k[kbi], self.d_x, 0, offset=4 * (32 * db + 8 * g4))
+        p.label("L_nopart%=")
         p.s_waitcnt(vmcnt=0)
         return p
 

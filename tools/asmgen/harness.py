@@ -40,7 +40,7 @@ def dkdv_block_params(N, Nk, D, Hq, Hkv, ns, window, kb):
 
 
 def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_races=True, blocks=None, stats=None,
-             stamped=False):
+             stamped=False, part_rows=0):
     """q, do [B, Hq, N, D]; k, v [B, Hkv, Nk, D] (torch, bf16 / f16); lse, delta [B, Hq, N] float.
     Returns dk, dv [B, Hkv, Nk, D] float32 (as stored by the kernel: 16-bit values)."""
     B, Hq, N, D = q.shape
@@ -55,6 +55,9 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
     adv = mem.alloc_zero(B * Hkv * Nk * D * 2)
     nkb = (Nk + 255) // 256
     dbg = mem.alloc_zero(B * Hkv * nkb * 64) if stamped else None
+    # part_rows > 0: every block also leaves the f32 partial of its first part_rows keys (the split sweeps' epilogue),
+    # [b, hk, block][dk | dv][part_rows][D]; returned as a third / fourth result
+    apart = mem.alloc_zero(B * Hkv * nkb * 2 * part_rows * D * 4) if part_rows else None
     for b in range(B):
         for hk in range(Hkv):
             for kb in range(nkb):
@@ -80,7 +83,13 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
                     q_sn=D * 2, do_sn=D * 2, k_sn=D * 2, v_sn=D * 2, dk_sn=D * 2, dv_sn=D * 2,
                     q_hs=N * D * 2, do_hs=N * D * 2, c_hs=2 * N * 4,
                     nq=bp["nq"], g=g, q_row0=bp["qt_lo"] * 32, kb0=bp["kb0"], pos0=bp["P"], W=bp["W"], ns=ns, nrows=N,
-                    cdelta=N * 4, c_log2=f32_bits(scale * math.log2(math.e)), scale=f32_bits(scale))
+                    cdelta=N * 4, c_log2=f32_bits(scale * math.log2(math.e)), scale=f32_bits(scale),
+                    pk_lo=0, pk_hi=0, pv_lo=0, pv_hi=0, p_rng=0)
+                if apart is not None:
+                    pb = apart + (((b * Hkv + hk) * nkb + kb) * 2 * part_rows * D) * 4 - bp["kb0"] * D * 4
+                    pvb = pb + part_rows * D * 4
+                    params.update(pk_lo=pb & 0xFFFFFFFF, pk_hi=pb >> 32, pv_lo=pvb & 0xFFFFFFFF, pv_hi=pvb >> 32,
+                                  p_rng=(bp["kb0"] + part_rows) * D * 4)
                 assert set(params) == set(K.PARAMS), set(params) ^ set(K.PARAMS)
                 if dbg is not None:      # stamped diagnostic body
                     params.update(dbg_lo=dbg & 0xFFFFFFFF, dbg_hi=dbg >> 32, bid=(b * Hkv + hk) * nkb + kb)
@@ -93,6 +102,9 @@ def run_dkdv(prog, q, k, v, do, lse, delta, ns, window, dtype="bf16", check_race
         raw = mem.read(addr).view(np.uint16).reshape(B, Hkv, Nk, D)
         t = torch.from_numpy(raw.view(np.int16).copy())
         return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+    if apart is not None:
+        pp = torch.from_numpy(mem.read(apart).view(np.float32).reshape(B, Hkv, nkb, 2, part_rows, D).copy())
+        return back(adk), back(adv), pp[:, :, :, 0], pp[:, :, :, 1]
     return back(adk), back(adv)
 
 
