@@ -24,7 +24,11 @@ Extra objects on the JSON line:
                 traffic_source names that file (it is NOT measured inside this run).
   cpu_baseline  the reference's eager fp32 algorithm (oracle/sink_oracle.py restatement, dense N x N, torch on all
                 host cores) timed on a bounded slice of the same workload (1 batch element x 1 KV group = 4 q heads),
-                rank 0 at N=1 only.
+                rank 0 at N=1 only: one warm-up repetition, then the median of three.
+  sustained     the same step run back to back for >= --sustain-seconds (default 2 s) AFTER the contract region (no stage
+                events, nothing else between the steps): ms_per_step / value once the chip has settled into the clock it
+                holds under this load (the 20-step contract region lasts ~0.12 s).  The contract fields above are
+                untouched by it.
 """
 import argparse
 import ctypes
@@ -66,7 +70,7 @@ class HipEvents:
         return ms.value if rc == 0 else float("nan")
 
 
-def cpu_baseline(w):
+def cpu_baseline(w, reps=3):
     """Dense eager fp32 attention fwd+bwd on host cores for 1 batch x 1 KV group of the workload."""
     from oracle import sink_oracle as O
     g = w["Hq"] // w["Hkv"]
@@ -77,16 +81,23 @@ def cpu_baseline(w):
     k = torch.randn(1, 1, N, D, generator=gen).requires_grad_(True)
     v = torch.randn(1, 1, N, D, generator=gen).requires_grad_(True)
     do = torch.randn(1, g, N, D, generator=gen)
-    t0 = time.perf_counter()
-    o, _ = O.sink_attention_dense(q, k, v, w["ns"], w["W"], dtype=torch.float32)
-    o.backward(do)
-    dt = time.perf_counter() - t0
+    times = []
+    for rep in range(1 + reps):                 # the first repetition warms up (allocator, thread pool) and is dropped
+        q.grad = k.grad = v.grad = None
+        t0 = time.perf_counter()
+        o, _ = O.sink_attention_dense(q, k, v, w["ns"], w["W"], dtype=torch.float32)
+        o.backward(do)
+        times.append(time.perf_counter() - t0)
+        del o
+    timed = sorted(times[1:])
+    dt = timed[len(timed) // 2]
     flops = O.flops_fwd_bwd(1, g, N, D, w["ns"], w["W"])
     return {"value": round(flops / dt / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"dense eager fp32 fwd+bwd of 1 batch x 1 KV group ({g} q heads) at N={N} D={D} ns={w['ns']} "
-                      f"W={w['W']}: {dt:.2f} s; per-(batch, KV head) work is independent, so the full workload is "
-                      f"{w['B'] * w['Hkv']}x this"}
+                      f"W={w['W']}: median {dt:.2f} s of {reps} repetitions ({', '.join('%.2f' % t for t in times[1:])}) "
+                      f"after one warm-up ({times[0]:.2f} s); per-(batch, KV head) work is independent, so the full "
+                      f"workload is {w['B'] * w['Hkv']}x this"}
 
 
 def pmc_traffic(kernel_key):
@@ -152,6 +163,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the contract region: back-to-back steps for at least this long (0: skip), reported as `sustained`")
     ap.add_argument("--dump-slice", default=None, metavar="PATH",
                     help="after the timed region run ONE more step and save the tensors of the last (batch, KV head) "
                          "unit (q, k, v, dO, O, dQ, dK, dV) to PATH: tests/test_gpu_bench_contract.py checks them "
@@ -234,6 +247,20 @@ def main():
                     "dv": cut(v.grad, slice(hk_, hk_ + 1)), "ns": ns, "W": W}, args.dump_slice)
         q.grad = k.grad = v.grad = None
 
+    # ---- sustained: the same step back to back for >= --sustain-seconds (DVFS steady state), same barrier / max-over-ranks
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        barrier()
+        dts = reduce_max_seconds(time.perf_counter() - t1, dev, world)
+        sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4),
+                     "value": round(job_value(f_fb, world, dts / n_sus), 2),
+                     "pct_mfma_peak": round(job_value(f_fb, world, dts / n_sus) / world / PEAK_BF16_TFLOPS * 100, 2)}
+
     if rank == 0:
         fwd_ms = sorted(s.elapsed_time(e) for s, e in fwd_ev)
         fwd_avg = sum(fwd_ms) / len(fwd_ms)
@@ -278,6 +305,8 @@ def main():
                        "algorithmic_gflop_per_step_per_gpu": round(f_fb / 1e9, 1)},
             "roofline": roofline,
         }
+        if sustained is not None:
+            line["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(line), flush=True)

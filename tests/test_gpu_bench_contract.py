@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_json_contract(tmp_path):
     dump = str(tmp_path / "slice.pt")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2",
-                          "--no-cpu-baseline", "--dump-slice", dump], capture_output=True, text=True, timeout=900,
+                          "--no-cpu-baseline", "--sustain-seconds", "0.5", "--dump-slice", dump], capture_output=True, text=True, timeout=900,
                          cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -38,6 +38,10 @@ def test_bench_json_contract(tmp_path):
     assert 100.0 < d["value"] < 2516.6
     assert set(r["per_kernel"]) == {"fwd", "bwd_dkdv", "bwd_dq"} and r["fwd_frac"] == r["per_kernel"]["fwd"]["frac"]
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+    # the sustained region: back-to-back steps for at least the requested time, same units, a plausible rate
+    su = d["sustained"]
+    assert su["seconds"] >= 0.5 and su["steps"] >= 3 and abs(su["ms_per_step"] - su["seconds"] / su["steps"] * 1e3) < 1e-2
+    assert 0.7 < su["value"] / d["value"] < 1.3
 
     # the numbers above must belong to a RIGHT answer: one (batch, KV head) unit of the bench's own tensors (results of
     # one more step on the same inputs) against the banded fp64 oracle, tolerances of the C3 parity test

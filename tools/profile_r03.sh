@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile set on the GPU box (outputs under gpurun_out/r02/, summaries copied to profiles/ by the builder):
+# Round-3 profile set on the GPU box (outputs under gpurun_out/r03/, summaries copied to profiles/ by the builder):
 #   1. contract bench line (python bench.py)
 #   2. rocprofv3 --kernel-trace --stats of the same command (per-kernel average durations)
 #   3. FETCH_SIZE / WRITE_SIZE PMC passes of the bench (separate runs, as the guide prescribes)
@@ -7,7 +7,7 @@
 #   5. kernel-trace stats + FETCH/WRITE_SIZE of the other BASELINE configs: C2 (fwd), C4 (fwd+bwd), C5 (decode)
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r02
+OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
@@ -21,7 +21,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CY
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/sq$i -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/sq$i.log 2>&1 || echo "group $i ($grp) failed"
 done
-cd $R && python tools/pmc_summary.py "gpurun_out/r02/pmc_*/**/*counter_collection.csv" "gpurun_out/r02/sq*/**/*counter_collection.csv" > $OUT/c3_pmc_summary.txt 2>&1
+cd $R && python tools/pmc_summary.py "gpurun_out/r03/pmc_*/**/*counter_collection.csv" "gpurun_out/r03/sq*/**/*counter_collection.csv" > $OUT/c3_pmc_summary.txt 2>&1
 cd /tmp
 # other configs: one process per config and pass
 for cfg in "fwd --cfg C2" "fwd bwd --cfg C4" "decode --cfg none"; do
@@ -31,6 +31,6 @@ for cfg in "fwd --cfg C2" "fwd bwd --cfg C4" "decode --cfg none"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${tag}_$c -o p -- python3 $R/tools/kbench.py $cfg --iters 4 > $OUT/pmc_${tag}_$c.log 2>&1 || echo "pmc $cfg $c failed"
   done
-  cd $R && python tools/pmc_summary.py "gpurun_out/r02/pmc_${tag}_*/**/*counter_collection.csv" > $OUT/${tag}_pmc_summary.txt 2>&1; cd /tmp
+  cd $R && python tools/pmc_summary.py "gpurun_out/r03/pmc_${tag}_*/**/*counter_collection.csv" > $OUT/${tag}_pmc_summary.txt 2>&1; cd /tmp
 done
 cat $OUT/bench.json; head -8 $OUT/c3_kernel_stats.csv; cat $OUT/c3_pmc_summary.txt
