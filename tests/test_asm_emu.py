@@ -199,3 +199,32 @@ def test_other_head_dims_in_emulator(D):
         for gen in (DkdvGen, DqGen, FwdGen):
             ok, err = assemble(_prog("bf16", True, gen, D))
             assert ok, err[:2000]
+
+
+@pytest.mark.parametrize("Hq,Hkv,N,D,W,NT,strip,dtype,aux,spike", [
+    (4, 1, 400, 80, 128, 3, 3, "bf16", True, False),      # gpt-oss sliding layer shape (C4): 3 tiles per item, strips of 3 + a ragged last
+    (8, 2, 300, 64, 100, 3, 5, "f16", False, False),      # no s_aux (rows start from m = -inf), window not a tile multiple, two KV heads
+    (4, 1, 260, 96, 64, 2, 2, "bf16", True, True),        # two tiles per item; a spiked key forces the out-of-line rescale
+    (4, 1, 330, 64, 192, 4, 6, "bf16", True, False),      # four tiles per item (5-slot ring), one strip over the whole sequence
+])
+def test_short_window_strip_forward_in_emulator(Hq, Hkv, N, D, W, NT, strip, dtype, aux, spike):
+    """tools/asmgen/fwd_strip.py: strips of consecutive query tiles over a sliding K / V ring, double-buffered Q fragments,
+    the finished item's stores under the next item's first MFMAs; against the oracle, under the emulator's wait / LDS-DMA
+    race checks; the first items of a sequence (tile indices below 0) go through the same blocks"""
+    from asmgen.fwd_strip import FwdStripGen
+    from asmgen.harness import run_fwd_strip
+    g = torch.Generator().manual_seed(N + D)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    q = torch.randn(1, Hq, N, D, generator=g).to(td)
+    k, v = (torch.randn(1, Hkv, N, D, generator=g).to(td) for _ in range(2))
+    if spike:
+        k[:, :, N - 30] = q[:, 0, N - 1] * 3
+    sa = torch.randn(Hq, generator=g) * 0.5 if aux else None
+    prog = FwdStripGen(dtype, D=D, NT=NT).build()
+    if os.path.exists(CLANG):
+        ok, err = assemble(prog)
+        assert ok, err[:2000]
+    o_ref, lse_ref = O.sink_attention_dense(q, k, v, 0, W, sa)
+    o, lse = run_fwd_strip(prog, q, k, v, W, sa, dtype, NT=NT, strip=strip)
+    assert (o.double() - o_ref).abs().max().item() < (1e-2 if dtype == "bf16" else 2e-3)
+    assert (lse.double() - lse_ref).abs().max().item() < 5e-3

@@ -63,11 +63,22 @@ class FwdStripGen(FwdGen):
         self.v_wt = va("v_wt")                                                     # mask threshold of the tile being masked
         self.vl = [va("vl%d" % rb) for rb in range(2)]                             # Q load offsets (next item)
         self.v_ls = [va("v_ls%d" % rb) for rb in range(2)]                         # LSE store offsets (finished item)
-        self.s_n, self.s_T = sa("s_n"), sa("s_T")                                  # items left, first tile of the current item
-        self.s_s0 = sa("s_s0")                                                     # ring offset of the current item's first tile
+        # registers of the finished item's epilogue (its own: it is spread over the gaps of the next item's first phases)
+        self.ep = [va("ep%d" % i, 4, 4) for i in range(4)]
+        self.ep_inv = [va("ep_inv%d" % rb) for rb in range(2)]
+        self.ep_lg = [va("ep_lg%d" % rb) for rb in range(2)]
+        self.ep_t = [va("ep_t%d" % i) for i in range(2)]
+        # (scalars of the one-item body that this walk does not use are taken over: s_it, s_k0n, s_st, s_stn, s_std, s_cls,
+        # s_rgi, s_pw0, s_pwhi)
+        spare = [self.s_it, self.s_k0n, self.s_st, self.s_stn, self.s_std, self.s_cls, self.s_rgi, self.s_pw0, self.s_pwhi]
+        take = lambda name: spare.pop() if spare else sa(name)
+        self.s_n, self.s_T = take("s_n"), take("s_T")                              # items left, first tile of the current item
+        self.s_s0 = take("s_s0")                                                   # ring offset of the current item's first tile
+        self.s_slot = [take("s_slot%d" % j) for j in range(NT)]                    # ring offsets of the current item's tiles
+        self.s_k0 = [take("s_k0_%d" % j) for j in range(NT)]                       # their first keys (signed)
+        self.s_m0 = take("s_m0")
         self.d_q = sa("d_q", 4, 4)
-        self.s_slot = [sa("s_slot%d" % j) for j in range(NT)]                      # ring offsets of the current item's tiles
-        self.s_k0 = [sa("s_k0_%d" % j) for j in range(NT)]                         # their first keys (signed)
+        self.d_x2 = sa("d_x2", 4, 4)
         self.uid = 0
 
     def params(self):
@@ -176,13 +187,13 @@ class FwdStripGen(FwdGen):
         """the finished item: O = O^T / l (l = 0 -> 1), LSE = ln2 (m + log2 l), stores; m of the finished item is read HERE,
         so this sits in front of the next item's M(t0) in program order"""
         dt = self.dtype
-        t0, t1, t2, t3, t4, t5 = self.tmp
-        inv, lg = [t4, t5], [self.v_d[0], self.v_d[1]]
+        t3, t2 = self.ep_t
+        inv, lg = self.ep_inv, self.ep_lg
         for rb in range(2):
             p.v_accvgpr_read(t3, self.LACC[rb][0])
             p.v_mov(t2, fimm(1.0))
-            p.v_cmp("eq_f32", 0, t3)
-            p.v_cndmask(t3, t3, t2)
+            p.v_cmp_m("eq_f32", self.s_f0, 0, t3)
+            p.v_cndmask_m(t3, t3, t2, self.s_f0)
             p.v_rcp_f32(inv[rb], t3)
             p.v_log_f32(lg[rb], t3)
             p.v_add_f32(lg[rb], self.m[rb], lg[rb])
@@ -193,7 +204,7 @@ class FwdStripGen(FwdGen):
                 for gp in range(2):
                     if 32 * db + 16 * gp >= self.D:
                         continue
-                    X, Y = self.POOL[2 + (2 * npair) % 8], self.POOL[2 + (2 * npair + 1) % 8]
+                    X, Y = self.ep[(2 * npair) % 4], self.ep[(2 * npair + 1) % 4]
                     npair += 1
                     for e in range(4):
                         p.v_accvgpr_read(X[e], self.OACC[rb][db][8 * gp + e])
@@ -429,9 +440,6 @@ class FwdStripGen(FwdGen):
         return p
 
     def build(self):
-        # extra registers the blocks need
-        self.d_x2 = self.sa("d_x2", 4, 4)
-        self.s_m0 = self.sa("s_m0")
         items = finish_block(self.prologue().items)
         nst = self.n_store()
         nq = 2 * self.DK

@@ -319,3 +319,51 @@ def run_fwd(prog, q, k, v, ns, window, s_aux=None, dtype="bf16", check_races=Tru
     o = t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
     lse = torch.from_numpy(mem.read(alse).view(np.float32).reshape(B, Hq, N).copy())
     return o, lse
+
+
+# ------------------------------------------------------------------------------------------------ short-window forward (strips)
+def run_fwd_strip(prog, q, k, v, window, s_aux=None, dtype="bf16", NT=3, strip=3, check_races=True, stats=None):
+    """q [B, Hq, N, D]; k, v [B, Hkv, N, D] (N_q = N_kv, no sink keys, GQA group a multiple of 4); every workgroup walks a
+    strip of `strip` consecutive 64-row query tiles of one (batch, KV head, head set).  Returns o f32, lse."""
+    from . import fwd_strip as KS
+    B, Hq, N, D = q.shape
+    Hkv = k.shape[1]
+    g = Hq // Hkv
+    assert g % 4 == 0 and k.shape[2] == N
+    scale = 1.0 / math.sqrt(D)
+    log2e = math.log2(math.e)
+    mem = Memory()
+    aq, ak, av = (mem.alloc(to_u16(t)) for t in (q, k, v))
+    ao = mem.alloc_zero(B * Hq * N * D * 2)
+    alse = mem.alloc_zero(B * Hq * N * 4)
+    nqt = (N + 63) // 64
+    rng = ((N - 1) * D + D) * 2
+    lo = lambda x: x & 0xFFFFFFFF
+    for b in range(B):
+        for hk in range(Hkv):
+            for hg in range(g // 4):
+                for s0 in range(0, nqt, strip):
+                    n_it = min(strip, nqt - s0)
+                    head0 = hk * g + hg * 4
+                    hb = (b * Hq + head0) * N
+                    kb = (b * Hkv + hk) * N * D * 2
+                    m0 = [f32_bits(float(s_aux[head0 + i]) * log2e) if s_aux is not None else KS.NEG_INF for i in range(4)]
+                    params = dict(
+                        q_lo=lo(aq + hb * D * 2), q_hi=(aq + hb * D * 2) >> 32, q_hs=N * D * 2, q_sn=D * 2, q_rng=rng,
+                        o_lo=lo(ao + hb * D * 2), o_hi=(ao + hb * D * 2) >> 32, o_hs=N * D * 2, o_sn=D * 2, o_rng=rng,
+                        k_lo=lo(ak + kb), k_hi=(ak + kb) >> 32, k_sn=D * 2, k_rng=rng,
+                        v_lo=lo(av + kb), v_hi=(av + kb) >> 32, v_sn=D * 2, v_rng=rng,
+                        lse_lo=lo(alse + hb * 4), lse_hi=(alse + hb * 4) >> 32, ld_hs=N * 4,
+                        m0_0=m0[0], m0_1=m0[1], m0_2=m0[2], m0_3=m0[3], l0=f32_bits(1.0 if s_aux is not None else 0.0),
+                        q0=64 * s0, n_it=n_it, nrows=N, W=min(max(window, 0), N), c_log2=f32_bits(scale * log2e),
+                        ln2=f32_bits(math.log(2.0)))
+                    assert set(params) == set(KS.PARAMS), set(params) ^ set(KS.PARAMS)
+                    wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+                    wg.run()
+                    if stats is not None:
+                        stats.append({"strip": (b, hk, hg, s0), "n_it": n_it, "icount": [w.icount for w in wg.waves]})
+    raw = mem.read(ao).view(np.uint16).reshape(B, Hq, N, D)
+    t = torch.from_numpy(raw.view(np.int16).copy())
+    o = t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+    lse = torch.from_numpy(mem.read(alse).view(np.float32).reshape(B, Hq, N).copy())
+    return o, lse

@@ -312,6 +312,10 @@ def fix_hazards(items: Sequence[Instr], loop: bool = False) -> List[Instr]:
         VALU write              -> v_permlane32_swap / v_readfirstlane of it                              :  2
         SALU write of M0        -> LDS-DMA                                                                :  1
         VALU write of an SGPR (v_readfirstlane) -> VMEM using it                                          :  5
+        buffer store of more than 64 bits -> a write of the VGPRs that hold its data                      :  2
+                                 (the store reads its data after it has issued: the finished item's stores of the strip
+                                 forward, spread by the scheduler, were followed at once by the next pair's v_accvgpr_read
+                                 into the same registers - garbage in every second column group on MI355X, right in the emulator)
     `loop`: the list is a loop body, the tail feeds the head (checked by running over two copies)."""
     def pass_once(seq: List[Instr], carry_in) -> (List[Instr], list):
         out: List[Instr] = []
@@ -350,6 +354,9 @@ def fix_hazards(items: Sequence[Instr], loop: bool = False) -> List[Instr]:
                 elif prev.kind == "salu":
                     if ("m0", 0) in pw and it.kind == "dma":
                         req = max(req, 1 - since)
+                elif prev.kind == "vstore":
+                    if prev.src[0].n > 2 and set(prev.src[0].regs()) & wr:
+                        req = max(req, 2 - since)
             return req
 
         for it in seq:
@@ -367,7 +374,7 @@ def fix_hazards(items: Sequence[Instr], loop: bool = False) -> List[Instr]:
             for h in hist:
                 h[1] += ws
             hist = [h for h in hist if h[1] < 16]
-            if it.kind in ("mfma", "valu", "trans", "salu"):
+            if it.kind in ("mfma", "valu", "trans", "salu", "vstore"):
                 hist.append([it, 0])
         return out, hist
 
