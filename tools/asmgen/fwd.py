@@ -221,10 +221,19 @@ class FwdGen(WorkList):
                 p.v_sub_u32(self.v_d[rb], self.v_pos[rb], t[1])        # pos - k0 - 4 h
                 if cls == 2 and rb == 0:
                     p.v_sub_u32(self.v_nsh, P("ns"), t[1])
+                if cls == 4:                                            # window only: key valid <=> c > (pos - k0 - 4 h) - W
+                    p.v_sub_u32(self.v_d[rb], self.v_d[rb], self.v_w)
                 for kh in range(2):
                     for v in range(16):
                         x = self.SS[par][kh][rb][v]
                         c = 32 * kh + (v & 3) + 8 * (v >> 2)
+                        if cls in (3, 4):
+                            # typed edges (one compare of the element's constant offset against a per-lane threshold): 3 = the
+                            # tile's keys are inside every row's window, only the causal test c <= pos - k0 - 4 h; 4 = every key
+                            # is causal, only the window test
+                            p.v_cmp("le_i32" if cls == 3 else "gt_i32", c, self.v_d[rb])
+                            p.v_cndmask(x, self.v_ninf, x)
+                            continue
                         p.v_sub_u32(t[0], self.v_d[rb], c)
                         if cls == 2:
                             p.v_cmp("lt_i32", c, self.v_nsh)
@@ -259,6 +268,12 @@ class FwdGen(WorkList):
             p.v_cndmask(tt, 0, mc)                                     # m_safe = m_new, 0 where m_new = -inf
             p.v_sub_f32(self.alpha[rb], self.m[rb], tt)
             p.v_exp_f32(self.alpha[rb], self.alpha[rb])
+            if getattr(self, "inf_no_rescale", False):
+                # a row that has seen nothing yet (m = -inf: O = 0, l = 0) needs no rescale when its reference point moves:
+                # alpha = 1 there, so the lane does not ask for the out-of-line pass (short windows without s_aux: the rows
+                # whose first tile is wholly outside their window would ask for it in every item)
+                p.v_cmp("neq_f32", self.v_ninf, self.m[rb])
+                p.v_cndmask(self.alpha[rb], fimm(1.0), self.alpha[rb])
             p.v_sub_f32(self.nms[rb], 0, tt)
             p.v_mov(self.m[rb], mc)
             p.v_cmp("neq_f32", fimm(1.0), self.alpha[rb])

@@ -49,6 +49,7 @@ class FwdStripGen(FwdGen):
                         kpre=False)
         self.NT, self.R = NT, NT + 1
         self.RING = self.R * STG_BYTES
+        self.inf_no_rescale = True
         va, sa = self.va, self.sa
         # ---------------- AGPRs: two Q buffers, row sums, ones, O^T
         DK, DB = self.DK, self.DB
@@ -61,6 +62,8 @@ class FwdStripGen(FwdGen):
         # ---------------- more VGPRs / SGPRs than the one-item body
         self.ak = [[va("ak%d%s" % (i, x)) for x in "eo"] for i in range(2)]       # K row-read addresses of two tiles in one block
         self.v_wt = va("v_wt")                                                     # mask threshold of the tile being masked
+        self.v_wc = va("v_wc")                                                     # W (steady blocks)
+        self.steady = False
         self.vl = [va("vl%d" % rb) for rb in range(2)]                             # Q load offsets (next item)
         self.v_ls = [va("v_ls%d" % rb) for rb in range(2)]                         # LSE store offsets (finished item)
         # registers of the finished item's epilogue (its own: it is spread over the gaps of the next item's first phases)
@@ -77,6 +80,7 @@ class FwdStripGen(FwdGen):
         self.s_slot = [take("s_slot%d" % j) for j in range(NT)]                    # ring offsets of the current item's tiles
         self.s_k0 = [take("s_k0_%d" % j) for j in range(NT)]                       # their first keys (signed)
         self.s_m0 = take("s_m0")
+        self.s_par = sa("s_par")
         self.d_q = sa("d_q", 4, 4)
         self.d_x2 = sa("d_x2", 4, 4)
         self.uid = 0
@@ -86,7 +90,7 @@ class FwdStripGen(FwdGen):
 
     def label(self, stem):
         self.uid += 1
-        return "L_%s%d%%=" % (stem, self.uid)
+        return "L_%s%d_%%=" % (stem, self.uid)
 
     # ------------------------------------------------------------------ small pieces
     def emit_wrap(self, p: Prog, dst, src, add):
@@ -129,7 +133,7 @@ class FwdStripGen(FwdGen):
                         p.s_mov_m0(t[1])
                     else:
                         p.s_add_m0(t[1], img + 2048 * e + 1024 * half)
-                    ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage",))
+                    ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage", "vmq"))
                     if spread_from is not None:
                         ins.mods["alap"] = spread_from + 200 * k
                     k += 1
@@ -138,6 +142,7 @@ class FwdStripGen(FwdGen):
         for rb in range(2):
             for ks in range(self.DK):
                 ins = p.buffer_load(self.QFB[buf][rb][ks], self.vl[rb], self.d_q, 0, offset=32 * ks)
+                ins.mem_w = ("vmq",)             # (the item's stores are ordered behind its requests in the memory queue, see build)
                 if spread_from is not None:
                     ins.mods["alap"] = spread_from + 120 * (rb * self.DK + ks)
 
@@ -149,7 +154,15 @@ class FwdStripGen(FwdGen):
         self.emit_A(p, par, e, o)
 
     def emit_M_at(self, p: Prog, par, j):
-        """mask / maximum / reference point of tile j in SS[par]: threshold W, or 0 for a tile index below 0"""
+        """mask / maximum / reference point of tile j in SS[par].  General blocks: the one-compare mask with threshold W, or 0
+        for a tile index below 0.  Steady blocks (every tile of the item exists, W >= 64): the last tile is the diagonal one
+        (causal test only), the others lie wholly below the rows (window test only) - two VALU per element instead of three."""
+        if self.steady:
+            keep = self.v_w
+            self.v_w = self.v_wc
+            self.emit_M(p, par, 3 if j == self.NT - 1 else 4, self.s_k0[j])
+            self.v_w = keep
+            return
         p.s_cmp("lt_i32", self.s_k0[j], 0)
         p.s_cselect(self.s_tmp[4], 0, P("W"))
         p.v_mov(self.v_wt, self.s_tmp[4])
@@ -218,9 +231,9 @@ class FwdStripGen(FwdGen):
                     p.v_cvt_pk(dt, X[3], Y[2], Y[3])
                     p.v_permlane32_swap(X[0], X[2])
                     p.v_permlane32_swap(X[1], X[3])
-                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
-        p.buffer_store(lg[0], self.v_ls[0], self.d_o2, 0)
-        p.buffer_store(lg[1], self.v_ls[1], self.d_o2, 0)
+                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp).mem_r = ("vmq",)
+        p.buffer_store(lg[0], self.v_ls[0], self.d_o2, 0).mem_r = ("vmq",)
+        p.buffer_store(lg[1], self.v_ls[1], self.d_o2, 0).mem_r = ("vmq",)
         # the next finished item sits 64 rows further
         p.s_lshl_b32(self.s_tmp[4], P("o_sn"), 6)
         for rb in range(2):
@@ -369,6 +382,7 @@ class FwdStripGen(FwdGen):
         for i in range(4):
             p.v_accvgpr_write(self.ONES[i], t1)
         p.v_mov(self.v_ninf, imm(NEG_INF))
+        p.v_mov(self.v_wc, P("W"))
         p.s_waitcnt(vmcnt=0, note="first item: its tiles and Q fragments")
         p.s_barrier()
         return p
@@ -397,11 +411,9 @@ class FwdStripGen(FwdGen):
             for rb in range(2):
                 p.v_add_u32(self.v_pos[rb], 64, self.v_pos[rb])
         self.emit_A_at(p, 0, 0, 0)
-        if not head:
-            self.emit_epilogue(p)                             # reads the finished item's m, l, O^T
-        self.emit_state_init(p)
-        self.emit_M_at(p, 0, 0)
-        # requests for the NEXT item: its Q fragments into the other buffer, its newest tile into the free ring slot
+        # requests for the NEXT item: its Q fragments into the other buffer, its newest tile into the free ring slot.  In
+        # program order they stand in FRONT of the finished item's stores, which depend on them ("vmq"): the stores are the
+        # youngest entries of the memory queue, so the wait at the next item's head can leave them in flight.
         p.s_lshl_b32(self.s_tmp[4], P("q_sn"), 6)
         for rb in range(2):
             p.v_add_u32(self.vl[rb], self.s_tmp[4], self.vl[rb])
@@ -409,6 +421,10 @@ class FwdStripGen(FwdGen):
         p.s_add_i32(self.s_tmp[3], self.s_T, NT)
         self.emit_wrap(p, self.s_tmp[2], self.s_slot[NT - 1], STG_BYTES)
         self.emit_dma(p, self.s_tmp[3], self.s_tmp[2], spread_from=600)
+        if not head:
+            self.emit_epilogue(p)                             # reads the finished item's m, l, O^T
+        self.emit_state_init(p)
+        self.emit_M_at(p, 0, 0)
         if NT >= 2:
             self.emit_A_at(p, 1, 1, 1)
         self.emit_E(p, 0)
@@ -451,7 +467,8 @@ class FwdStripGen(FwdGen):
                 b = schedule(b)
             return fix_hazards(insert_waits(b))
 
-        def item_blocks(buf, head):
+        def item_blocks(buf, head, steady=False):
+            self.steady = steady
             out = []
             out += block(self.big(buf, head))
             p = Prog()
@@ -462,27 +479,43 @@ class FwdStripGen(FwdGen):
                 p = Prog()
                 self.emit_rescale_check(p)
                 out += finish_block(p.items)
+            self.steady = False
             return out
 
-        # first item (Q buffer 0), then the loop: items alternate between the Q buffers
+        # the strip's first item (Q buffer 0, general masks), then the loop: items alternate between the Q buffers; an item
+        # whose tiles all exist (first tile index >= 0) takes the steady blocks when the window spans a whole tile
         items += item_blocks(0, True)
         p = Prog()
-        p.label("L_next1%=")
+        p.s_mov(self.s_par, 1)
         p.s_cmp("le_u32", self.s_n, 1)
         p.s_cbranch("scc1", "L_tail%=")
-        # this wave's requests of the last item (Q fragments, tile pieces) have landed: everything but the youngest stores
-        p.s_waitcnt(vmcnt=0, note="next item's Q fragments and newest tile (own pieces)")
-        p.s_barrier()
-        items += finish_block(p.items)
-        items += item_blocks(1, False)
-        p = Prog()
+        p.s_waitcnt(vmcnt=0, note="second item's Q fragments and newest tile (the first item has left no stores behind)")
+        p.s_branch("L_disp%=")
+        p.label("L_next%=")
         p.s_cmp("le_u32", self.s_n, 1)
         p.s_cbranch("scc1", "L_tail%=")
-        p.s_waitcnt(vmcnt=0)
+        # this wave's requests of the last item (Q fragments, tile pieces) have landed; its stores - issued BEHIND the requests
+        # (the "vmq" dependence) - may still be in flight
+        p.s_waitcnt(vmcnt=nst, note="next item's Q fragments and newest tile (own pieces)")
+        p.label("L_disp%=")
         p.s_barrier()
+        # the NEXT item's first tile is s_T + 1 (the advance happens inside its BIG block)
+        p.s_cmp("ge_i32", self.s_T, -1)
+        p.s_cselect(self.s_tmp[0], 2, 0)
+        p.s_cmp("ge_u32", P("W"), 64)
+        p.s_cselect(self.s_tmp[0], self.s_tmp[0], 0)
+        p.s_or_b32(self.s_tmp[0], self.s_tmp[0], self.s_par)
+        for code in (3, 2, 1):
+            p.s_cmp("eq_u32", self.s_tmp[0], code)
+            p.s_cbranch("scc1", "L_it%d_%%=" % code)
         items += finish_block(p.items)
-        items += item_blocks(0, False)
-        items.append(Instr("s_branch", mods={"label": "L_next1%="}, kind="branch"))
+        for code in (0, 3, 2, 1):
+            p = Prog()
+            p.label("L_it%d_%%=" % code)
+            p.s_mov(self.s_par, (code & 1) ^ 1)
+            items += finish_block(p.items)
+            items += item_blocks(code & 1, False, steady=bool(code & 2))
+            items.append(Instr("s_branch", mods={"label": "L_next%="}, kind="branch"))
         p = Prog()
         p.label("L_tail%=")
         items += finish_block(p.items)

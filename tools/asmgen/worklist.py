@@ -45,7 +45,7 @@ class WorkList:
 
     def wl_label(self, stem):
         self._wl_uid += 1
-        return "L_%s%d%%=" % (stem, self._wl_uid)
+        return "L_%s%d_%%=" % (stem, self._wl_uid)
 
     # ------------------------------------------------------------------ descriptor access
     def desc_read(self, p: Prog, item, groups, land, addr):
