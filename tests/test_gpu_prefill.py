@@ -487,6 +487,7 @@ def test_small_grids_row_split_or_compiled_dkdv_kernel():
         for (B, Hq, Hkv, N, Nk, D, ns, W, want) in ((1, 4, 1, 2048, 2048, 128, 4, 512, "dkdvasm4x64"),      # one KV head: 8 blocks
                                                     (1, 4, 1, 1500, 1500, 64, 300, 700, "dkdvasm4x64"),     # sinks over two blocks
                                                     (2, 4, 2, 1000, 1000, 128, 0, 1000, "dkdvasm4x64"),     # causal, no sinks
+                                                    (1, 4, 1, 257, 257, 128, 130, 0, "dkdvasm4x64"),        # window 0: a split block NO row sees
                                                     (1, 8, 2, 1024, 1200, 128, 4, 4096, "dkdvws8"),         # N_q < N_kv
                                                     (2, 4, 1, 300, 1500, 128, 4, 700, "dkdvws8"),           # N_q << N_kv, window edge inside
                                                     (1, 8, 8, 512, 700, 96, 0, 400, "dkdvws8"),             # MHA, no sinks, head dim 96

@@ -155,12 +155,15 @@ class FwdStripGen(FwdGen):
 
     def emit_M_at(self, p: Prog, par, j):
         """mask / maximum / reference point of tile j in SS[par].  General blocks: the one-compare mask with threshold W, or 0
-        for a tile index below 0.  Steady blocks (every tile of the item exists, W >= 64): the last tile is the diagonal one
-        (causal test only), the others lie wholly below the rows (window test only) - two VALU per element instead of three."""
+        for a tile index below 0.  Steady blocks (every tile of the item exists, W = 64 (NT - 1) or one more - the gpt-oss
+        window of 128): the last tile is the diagonal one (causal test only), the first lies wholly below the rows (window test
+        only; two VALU per element instead of three), the ones between need no mask."""
         if self.steady:
             keep = self.v_w
             self.v_w = self.v_wc
-            self.emit_M(p, par, 3 if j == self.NT - 1 else 4, self.s_k0[j])
+            # (steady blocks run only when W = 64 (NT - 1) or one more: the tiles between the first and the diagonal one are
+            # then wholly inside every row's window and need no mask at all)
+            self.emit_M(p, par, 3 if j == self.NT - 1 else (4 if j == 0 else 0), self.s_k0[j])
             self.v_w = keep
             return
         p.s_cmp("lt_i32", self.s_k0[j], 0)
@@ -502,7 +505,8 @@ class FwdStripGen(FwdGen):
         # the NEXT item's first tile is s_T + 1 (the advance happens inside its BIG block)
         p.s_cmp("ge_i32", self.s_T, -1)
         p.s_cselect(self.s_tmp[0], 2, 0)
-        p.s_cmp("ge_u32", P("W"), 64)
+        p.s_sub_u32(self.s_tmp[1], P("W"), 64 * (self.NT - 1))          # steady blocks: W = 64 (NT - 1) or one more (see emit_M_at)
+        p.s_cmp("le_u32", self.s_tmp[1], 1)
         p.s_cselect(self.s_tmp[0], self.s_tmp[0], 0)
         p.s_or_b32(self.s_tmp[0], self.s_tmp[0], self.s_par)
         for code in (3, 2, 1):
