@@ -250,13 +250,18 @@ def main():
     # ---- sustained: the same step back to back for >= --sustain-seconds (DVFS steady state), same barrier / max-over-ranks
     sustained = None
     if args.sustain_seconds > 0:
-        n_sus = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n_sus):
-            step()
-        barrier()
-        dts = reduce_max_seconds(time.perf_counter() - t1, dev, world)
+        n_sus, dts = 0, 0.0
+        per = max(dt / args.steps, 1e-6)
+        while dts < args.sustain_seconds:                    # (regions are added up until the requested time is reached)
+            n = max(args.steps, int((args.sustain_seconds - dts) / per * 1.05) + 1)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            barrier()
+            d1 = reduce_max_seconds(time.perf_counter() - t1, dev, world)
+            n_sus, dts = n_sus + n, dts + d1
+            per = max(dts / n_sus, 1e-6)
         sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4),
                      "value": round(job_value(f_fb, world, dts / n_sus), 2),
                      "pct_mfma_peak": round(job_value(f_fb, world, dts / n_sus) / world / PEAK_BF16_TFLOPS * 100, 2)}

@@ -228,3 +228,30 @@ def test_short_window_strip_forward_in_emulator(Hq, Hkv, N, D, W, NT, strip, dty
     o, lse = run_fwd_strip(prog, q, k, v, W, sa, dtype, NT=NT, strip=strip)
     assert (o.double() - o_ref).abs().max().item() < (1e-2 if dtype == "bf16" else 2e-3)
     assert (lse.double() - lse_ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("Hq,Hkv,N,D,W,NT,strip,dtype", [
+    (4, 1, 400, 80, 128, 3, 3, "bf16"),      # gpt-oss sliding layer shape (C4): 3 tiles per item, steady blocks after the first two items
+    (8, 2, 300, 64, 100, 3, 5, "f16"),       # window not a tile multiple (general blocks throughout), two KV heads
+    (4, 1, 330, 64, 192, 4, 6, "bf16"),      # four tiles per item (5-slot ring), one strip over the whole sequence
+])
+def test_short_window_strip_dq_in_emulator(Hq, Hkv, N, D, W, NT, strip, dtype):
+    """tools/asmgen/dq_strip.py: the backward twin of the strip forward (sliding K / V ring, double-buffered Q / dO fragments
+    and row constants, the finished item's dQ stores under the next item's MFMAs), against the oracle under the emulator's
+    wait / LDS-DMA race checks"""
+    from asmgen.dq_strip import DqStripGen
+    from asmgen.harness import run_dq_strip
+    g = torch.Generator().manual_seed(N + D)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    q, do = (torch.randn(1, Hq, N, D, generator=g).to(td) for _ in range(2))
+    k, v = (torch.randn(1, Hkv, N, D, generator=g).to(td) for _ in range(2))
+    o, lse = O.sink_attention_dense(q, k, v, 0, W)
+    delta = (do.double() * o).sum(-1)
+    dq_ref, _, _, _ = O.sink_attention_bwd_dense(q, k, v, do, 0, W)
+    prog = DqStripGen(dtype, D=D, NT=NT).build()
+    if os.path.exists(CLANG):
+        ok, err = assemble(prog)
+        assert ok, err[:2000]
+    dq = run_dq_strip(prog, q, k, v, do, lse, delta, W, dtype, NT=NT, strip=strip)
+    err = (dq.double() - dq_ref).abs()
+    assert (err <= 5e-2 + 5e-2 * dq_ref.abs()).all() and err.max().item() < 3e-2, err.max().item()

@@ -59,13 +59,14 @@ def dkdv_kernel_name(mode, B, Hkv, Nq, Nk, D, window, packed=False, dtype=torch.
     if dtype == torch.float32 or D not in (64, 80, 96, 128):
         return None
     W = min(max(window, 0), Nk)
-    if not (D == 128 or W > 256):          # short windows below head dim 128: compiled kernels only
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    wgs = -(-Nk // 256) * Hkv * B
+    if not (D == 128 or W > 256 or wgs >= 2 * n_cu):   # short windows below head dim 128 on a grid that does not fill the chip twice: compiled kernels only
         return "dkdvws8"
     if mode == "asm":
         return "dkdvasm4x64"
     if mode == "ws":
         return "dkdvws8"
-    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     dense = (not packed) and Nq == Nk      # row split available: the hand-placed kernel fills the chip whatever the grid
     fills = -(-Nk // 256) * Hkv * B >= n_cu
     return "dkdvasm4x64" if (dense or fills) else "dkdvws8"

@@ -64,6 +64,7 @@ class FwdStripGen(FwdGen):
         self.v_wt = va("v_wt")                                                     # mask threshold of the tile being masked
         self.v_wc = va("v_wc")                                                     # W (steady blocks)
         self.steady = False
+        self.st_from, self.st_step, self.ld_step = None, 0, 1
         self.vl = [va("vl%d" % rb) for rb in range(2)]                             # Q load offsets (next item)
         self.v_ls = [va("v_ls%d" % rb) for rb in range(2)]                         # LSE store offsets (finished item)
         # registers of the finished item's epilogue (its own: it is spread over the gaps of the next item's first phases)
@@ -87,6 +88,12 @@ class FwdStripGen(FwdGen):
 
     def params(self):
         return list(PARAMS)
+
+    @staticmethod
+    def gate(ins, k):
+        """not before the k-th MFMA of the block, and right there (sched.py: after_mfma)"""
+        ins.mods["after_mfma"] = int(k)
+        ins.mods["alap"] = 32 * (int(k) + 1)
 
     def label(self, stem):
         self.uid += 1
@@ -133,18 +140,17 @@ class FwdStripGen(FwdGen):
                         p.s_mov_m0(t[1])
                     else:
                         p.s_add_m0(t[1], img + 2048 * e + 1024 * half)
-                    ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage", "vmq"))
+                    ins = p.buffer_load_lds(16, vt, desc, 0, mem=("dma_stage",))
                     if spread_from is not None:
-                        ins.mods["alap"] = spread_from + 200 * k
+                        self.gate(ins, spread_from + 2 * k)
                     k += 1
 
     def emit_q_loads(self, p: Prog, buf, spread_from=None):
         for rb in range(2):
             for ks in range(self.DK):
                 ins = p.buffer_load(self.QFB[buf][rb][ks], self.vl[rb], self.d_q, 0, offset=32 * ks)
-                ins.mem_w = ("vmq",)             # (the item's stores are ordered behind its requests in the memory queue, see build)
-                if spread_from is not None:
-                    ins.mods["alap"] = spread_from + 120 * (rb * self.DK + ks)
+                if spread_from is not None:      # (spread: the CU's address path takes ~56 cycles per such load)
+                    self.gate(ins, spread_from + self.ld_step * (rb * self.DK + ks))
 
     def emit_A_at(self, p: Prog, par, j, i):
         """S^T of the item's tile j into SS[par]; address register pair i"""
@@ -234,9 +240,11 @@ class FwdStripGen(FwdGen):
                     p.v_cvt_pk(dt, X[3], Y[2], Y[3])
                     p.v_permlane32_swap(X[0], X[2])
                     p.v_permlane32_swap(X[1], X[3])
-                    p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp).mem_r = ("vmq",)
-        p.buffer_store(lg[0], self.v_ls[0], self.d_o2, 0).mem_r = ("vmq",)
-        p.buffer_store(lg[1], self.v_ls[1], self.d_o2, 0).mem_r = ("vmq",)
+                    ins = p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
+                    if self.st_from is not None:
+                        self.gate(ins, self.st_from + self.st_step * (npair - 1))
+        p.buffer_store(lg[0], self.v_ls[0], self.d_o2, 0)
+        p.buffer_store(lg[1], self.v_ls[1], self.d_o2, 0)
         # the next finished item sits 64 rows further
         p.s_lshl_b32(self.s_tmp[4], P("o_sn"), 6)
         for rb in range(2):
@@ -420,10 +428,18 @@ class FwdStripGen(FwdGen):
         p.s_lshl_b32(self.s_tmp[4], P("q_sn"), 6)
         for rb in range(2):
             p.v_add_u32(self.vl[rb], self.s_tmp[4], self.vl[rb])
-        self.emit_q_loads(p, buf ^ 1, spread_from=400)
+        # positions (MFMA indices of the BIG block: 8 DB + 8 of the previous item's last PV, 8 DK of A(t0), 8 DK of A(t1), then
+        # C(t0)): the finished item's stores and the next item's loads interleave between the end of the previous PV and C(t0)
+        # - the stores must be out before C(t0) writes the accumulators - the tile's DMA pieces go under C(t0)
+        n0 = 0 if head else 8 * self.DB + 8
+        n1 = n0 + 16 * self.DK
+        nld, nst = 2 * self.DK, self.n_store() - 2
+        self.ld_step = max(1, (n1 - n0 - 2) // nld)
+        self.st_from, self.st_step = (None, 0) if head else (n0 + 2, max(1, (n1 - n0 - 4) // nst))
+        self.emit_q_loads(p, buf ^ 1, spread_from=n0 + 1)
         p.s_add_i32(self.s_tmp[3], self.s_T, NT)
         self.emit_wrap(p, self.s_tmp[2], self.s_slot[NT - 1], STG_BYTES)
-        self.emit_dma(p, self.s_tmp[3], self.s_tmp[2], spread_from=600)
+        self.emit_dma(p, self.s_tmp[3], self.s_tmp[2], spread_from=n1 + 4)
         if not head:
             self.emit_epilogue(p)                             # reads the finished item's m, l, O^T
         self.emit_state_init(p)
@@ -497,9 +513,7 @@ class FwdStripGen(FwdGen):
         p.label("L_next%=")
         p.s_cmp("le_u32", self.s_n, 1)
         p.s_cbranch("scc1", "L_tail%=")
-        # this wave's requests of the last item (Q fragments, tile pieces) have landed; its stores - issued BEHIND the requests
-        # (the "vmq" dependence) - may still be in flight
-        p.s_waitcnt(vmcnt=nst, note="next item's Q fragments and newest tile (own pieces)")
+        p.s_waitcnt(vmcnt=0, note="next item's Q fragments and newest tile (own pieces)")
         p.label("L_disp%=")
         p.s_barrier()
         # the NEXT item's first tile is s_T + 1 (the advance happens inside its BIG block)

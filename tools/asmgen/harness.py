@@ -367,3 +367,45 @@ def run_fwd_strip(prog, q, k, v, window, s_aux=None, dtype="bf16", NT=3, strip=3
     o = t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
     lse = torch.from_numpy(mem.read(alse).view(np.float32).reshape(B, Hq, N).copy())
     return o, lse
+
+
+def run_dq_strip(prog, q, k, v, do, lse, delta, window, dtype="bf16", NT=3, strip=3, check_races=True):
+    """q, do [B, Hq, N, D]; k, v [B, Hkv, N, D]; lse, delta [B, Hq, N] (N_q = N_kv, no sink keys, GQA group a multiple of 4):
+    every workgroup walks a strip of `strip` consecutive 64-row query tiles.  Returns dq f32."""
+    from . import dq_strip as KS
+    B, Hq, N, D = q.shape
+    Hkv = k.shape[1]
+    g = Hq // Hkv
+    assert g % 4 == 0 and k.shape[2] == N
+    scale = 1.0 / math.sqrt(D)
+    mem = Memory()
+    aq, ak, av, ado = (mem.alloc(to_u16(t)) for t in (q, k, v, do))
+    alse = mem.alloc(lse.float().contiguous().numpy())
+    adl = mem.alloc(delta.float().contiguous().numpy())
+    adq = mem.alloc_zero(B * Hq * N * D * 2)
+    nqt = (N + 63) // 64
+    rng = ((N - 1) * D + D) * 2
+    lo = lambda x: x & 0xFFFFFFFF
+    for b in range(B):
+        for hk in range(Hkv):
+            for hg in range(g // 4):
+                for s0 in range(0, nqt, strip):
+                    n_it = min(strip, nqt - s0)
+                    head0 = hk * g + hg * 4
+                    hb = (b * Hq + head0) * N
+                    kb = (b * Hkv + hk) * N * D * 2
+                    params = dict(
+                        q_lo=lo(aq + hb * D * 2), q_hi=(aq + hb * D * 2) >> 32, q_hs=N * D * 2, q_sn=D * 2, q_rng=rng,
+                        do_lo=lo(ado + hb * D * 2), do_hi=(ado + hb * D * 2) >> 32, do_hs=N * D * 2, do_sn=D * 2, do_rng=rng,
+                        dq_lo=lo(adq + hb * D * 2), dq_hi=(adq + hb * D * 2) >> 32, dq_hs=N * D * 2, dq_sn=D * 2, dq_rng=rng,
+                        k_lo=lo(ak + kb), k_hi=(ak + kb) >> 32, k_sn=D * 2, k_rng=rng,
+                        v_lo=lo(av + kb), v_hi=(av + kb) >> 32, v_sn=D * 2, v_rng=rng,
+                        lse_lo=lo(alse + hb * 4), lse_hi=(alse + hb * 4) >> 32, dl_lo=lo(adl + hb * 4), dl_hi=(adl + hb * 4) >> 32,
+                        ld_hs=N * 4, q0=64 * s0, n_it=n_it, nrows=N, W=min(max(window, 0), N),
+                        c_log2=f32_bits(scale * math.log2(math.e)), nlog2e=f32_bits(-math.log2(math.e)), scale=f32_bits(scale))
+                    assert set(params) == set(KS.PARAMS), set(params) ^ set(KS.PARAMS)
+                    wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+                    wg.run()
+    raw = mem.read(adq).view(np.uint16).reshape(B, Hq, N, D)
+    t = torch.from_numpy(raw.view(np.int16).copy())
+    return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()

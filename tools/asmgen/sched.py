@@ -95,7 +95,10 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
     latest issue time that still lets everything depending on it meet that (LDS latency 128, MFMA result 64, ...).
     In every gap the ready instruction with the earliest deadline goes first; one that does not fit into the gap is
     placed anyway when the next MFMA's ideal start is past its deadline (it would stall that or a later MFMA),
-    otherwise the MFMA goes.  `mods["alap"]` overrides a deadline (LDS-DMA: early in the block, see the kernels)."""
+    otherwise the MFMA goes.  `mods["alap"]` overrides a deadline (LDS-DMA: early in the block, see the kernels);
+    `mods["after_mfma"] = k` keeps an instruction behind the k-th MFMA of the spine (the strip kernels spread their global
+    requests over an item's block this way, with `alap` = 32 (k + 1) so that it goes out right there: the CU's address path
+    takes ~56 cycles per fragment load and blocks the in-order wave when requests come in a burst)."""
     items = list(items)
     n = len(items)
     deps = build_deps(items)
@@ -193,6 +196,8 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
             slip = max(0.0, start - ideal_next)
             best = None
             for i in fillers:
+                if items[i].mods.get("after_mfma", 0) > next_spine:
+                    continue                      # "not before the k-th MFMA": spreads global requests over a long block
                 dr = max(data_ready(i), t)
                 if items[i].kind == "ds_read" and not lds_room(dr):
                     continue                      # the LDS queue is full: reads wait for a later gap
@@ -210,6 +215,9 @@ def schedule(items: Sequence[Instr], verbose: bool = False, trace=None) -> List[
             continue
         if not fillers:
             raise RuntimeError("scheduler stuck: dependence cycle?")
+        open_f = [i for i in fillers if items[i].mods.get("after_mfma", 0) <= next_spine]
+        if open_f:
+            fillers = open_f                      # (gated fillers go only when nothing else can: the MFMA they wait behind needs them)
         # the next MFMA waits for fillers: most urgent first
         cand = sorted((alap[i], i) for i in fillers)
         i = cand[0][1]
