@@ -255,3 +255,34 @@ def test_short_window_strip_dq_in_emulator(Hq, Hkv, N, D, W, NT, strip, dtype):
     dq = run_dq_strip(prog, q, k, v, do, lse, delta, W, dtype, NT=NT, strip=strip)
     err = (dq.double() - dq_ref).abs()
     assert (err <= 5e-2 + 5e-2 * dq_ref.abs()).all() and err.max().item() < 3e-2, err.max().item()
+
+
+# ------------------------------------------------------------------------------------------------ skewed dK/dV sweep
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,W,dtype", [
+    (1, 2, 1, 300, 80, 128, "bf16"),      # the gpt-oss window: T = 6, two key blocks, ragged last slice
+    (1, 3, 1, 520, 64, 100, "bf16"),      # three blocks, group of 3
+    (1, 2, 2, 333, 64, 200, "f16"),       # T = 9: trips without a B slice; MHA
+    (2, 1, 1, 257, 96, 33, "bf16")])      # T rounded up to 6; a last block of one key
+def test_dkdv_skew_body_in_emulator_matches_oracle(B, Hq, Hkv, N, D, W, dtype):
+    """the short-window dK/dV body (tools/asmgen/dkdv_skew.py: wave w on slice r of head h or slice T + r of head h - 1)"""
+    from asmgen.dkdv_skew import DkdvSkewGen
+    from asmgen.harness import run_dkdv_skew
+    q, k, v, do, lse, delta, dk, dv = _case(B, Hq, Hkv, N, N, 0, W, dtype, seed=N, D=D)
+    dk_e, dv_e = run_dkdv_skew(DkdvSkewGen(dtype, D=D).build(), q, k, v, do, lse, delta, W, dtype)
+    for got, ref, name in ((dk_e, dk, "dk"), (dv_e, dv, "dv")):
+        err = (got.double() - ref).abs()
+        assert (err <= 1e-1 + 5e-2 * ref.abs()).all(), (name, err.max().item())
+        assert err.max().item() < 4e-2, (name, err.max().item())
+
+
+def test_dkdv_skew_scheduled_equals_program_order_and_assembles():
+    from asmgen.dkdv_skew import DkdvSkewGen
+    from asmgen.harness import run_dkdv_skew
+    q, k, v, do, lse, delta, _, _ = _case(1, 2, 1, 300, 300, 0, 128, "bf16", seed=300, D=80)
+    a = run_dkdv_skew(DkdvSkewGen("bf16", D=80, sched=False).build(), q, k, v, do, lse, delta, 128, "bf16")
+    b = run_dkdv_skew(DkdvSkewGen("bf16", D=80).build(), q, k, v, do, lse, delta, 128, "bf16")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    if os.path.exists(CLANG):
+        for D in (64, 80, 96):
+            ok, err = assemble(DkdvSkewGen("bf16", D=D).build())
+            assert ok, err[:4000]

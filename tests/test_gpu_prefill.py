@@ -221,7 +221,7 @@ def test_extended_backward(B, Hq, Hkv, N, D, ns, W, dkdv):
     dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W)
     qt, kt, vt = (t.half().to(DEV).requires_grad_(True) for t in (q, k, v))
     _op()(qt, kt, vt, num_sink=ns, window_size=W).backward(do.half().to(DEV))
-    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W) in _path(), _path()
+    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W, ns=ns) in _path(), _path()
     assert_close(qt.grad.float(), dq_r, 5e-2, 5e-2, "dq")
     assert_close(kt.grad.float(), dk_r, 5e-2, 5e-2, "dk")
     assert_close(vt.grad.float(), dv_r, 5e-2, 5e-2, "dv")
@@ -297,7 +297,7 @@ def test_shapes_fwd_bwd(B, Hq, Hkv, N, D, ns, W, aux, dtype, dkdv):
     sad = sa.to(DEV).requires_grad_(True) if aux else None
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     out.backward(do.to(DEV))
-    want = dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W, dtype=dtype)
+    want = dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W, dtype=dtype, ns=ns)
     assert want is None or want in _path(), (want, _path())
     to, tg = {torch.float32: (2e-5, 2e-4), torch.float16: (4e-3, 3e-2), torch.bfloat16: (2e-2, 1.5e-1)}[dtype]
     assert maxdiff(out, o_r) < to, f"o ({_path()})"
@@ -361,7 +361,7 @@ def test_backward_with_many_kv_groups(B, Hkv, dkdv):
     sad = sa.to(DEV).requires_grad_(True)
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     out.backward(do.to(DEV))
-    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W) in _path(), _path()      # (dense batch: the hand-placed kernel + row split either way)
+    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W, ns=ns) in _path(), _path()      # (dense batch: the hand-placed kernel + row split either way)
     o_r, _ = oracle_fwd(q, k, v, ns, W, sa)
     dq_r, dk_r, dv_r, dsa_r = oracle_bwd(q, k, v, do, ns, W, sa)
     assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "fwd")
@@ -467,7 +467,7 @@ def test_sink_split_of_the_dkdv_sweep(B, Hq, Hkv, N, Nk, D, ns, W, dtype, dkdv):
         sad = sa.to(DEV).requires_grad_(True)
         out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
         out.backward(do.to(DEV))
-        assert dkdv_kernel_name(dkdv, B, Hkv, N, Nk, D, W) in _path(), _path()
+        assert dkdv_kernel_name(dkdv, B, Hkv, N, Nk, D, W, ns=ns) in _path(), _path()
         grads.append((qd.grad.clone(), kd.grad.clone(), vd.grad.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*grads))
     dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, ns, W, sa)
@@ -524,7 +524,10 @@ def test_baseline_c4_full_shape(dkdv):
     sad = sa.to(DEV).requires_grad_(True)
     out = _op()(qd, kd, vd, num_sink=ns, window_size=W, s_aux=sad)
     out.backward(do.to(DEV))
-    assert "dkdvws8" in _path(), _path()            # D = 80, W = 128: the compiled short-window kernels in both modes
+    # D = 80, W = 128, no sink keys: the skewed-sweep kernel under the rule; forced: the plain hand-placed kernel would need a grid
+    # that fills the chip twice (256 blocks here), so the compiled one
+    assert dkdv_kernel_name(dkdv, B, Hkv, N, N, D, W, ns=ns) in _path(), _path()
+    assert ("dkdvasmskew" in _path()) == (dkdv == "rule"), _path()
     assert_close(out, o_r.bfloat16(), 2e-2, 2e-2, "C4 fwd")
     assert_close(qd.grad, dq_r, 5e-2, 5e-2, "C4 dq")
     assert_close(kd.grad, dk_r, 5e-2 * max(1.0, dk_r.abs().max().item()), 5e-2, "C4 dk")
@@ -557,6 +560,50 @@ def test_baseline_config_shapes_against_banded_oracle(cfg, dkdv):
         assert_close(vd.grad, dv_r, 5e-2 * max(1.0, dv_r.abs().max().item()), 5e-2, cfg + " dv")
         if aux:
             assert maxdiff(sad.grad, dsa_r) < 5e-2 * max(1.0, dsa_r.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,N,D,W,dtype,layout", [
+    (1, 8, 1, 777, 80, 128, torch.bfloat16, "bhnd"),      # the gpt-oss group of 8, ragged last block / last slice
+    (2, 2, 2, 1000, 64, 33, torch.float16, "bnhd"),       # MHA, short window (T rounded up to 6), [B, N, H, D] views
+    (1, 6, 2, 530, 96, 200, torch.bfloat16, "bhnd"),      # T = 9 > 6 (trips without a B slice), group of 3
+    (3, 4, 1, 256, 64, 512, torch.bfloat16, "bnhd"),      # window longer than the sequence, one block
+    (1, 2, 1, 40, 80, 1, torch.float16, "bhnd"),          # window of one key, a sequence shorter than a wave's keys
+    (2, 16, 2, 2048, 64, 128, torch.bfloat16, "bnhd")])   # many blocks per group
+def test_short_window_skewed_dkdv_sweep(B, Hq, Hkv, N, D, W, dtype, layout):
+    """No sink keys + a short window at head dims 64 / 80 / 96: bwd_dkdv_skew_asm_kernel (tools/asmgen/dkdv_skew.py) under
+    the rule, against the oracle and against the plain hand-placed / compiled kernels of the same library (per-call flags);
+    bitwise deterministic."""
+    from sink_attention import set_backward_options
+    q, k, v, g = make_qkv(B, Hq, Hkv, N, D, dtype, seed=N + W)
+    do = rand((B, Hq, N, D), g, dtype)
+    sa = rand((Hq,), g, torch.float32, 0.5)
+    dq_r, dk_r, dv_r, _ = oracle_bwd(q, k, v, do, 0, W, sa, banded=N > 600)
+    res = {}
+    prev = set_backward_options(dkdv="rule")
+    try:
+        for mode in ("rule", "rule", "ws"):
+            set_backward_options(dkdv=mode)
+            if layout == "bnhd":
+                qd, kd, vd = (t.transpose(1, 2).contiguous().to(DEV).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+                dod = do.transpose(1, 2).contiguous().to(DEV).transpose(1, 2)
+            else:
+                qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+                dod = do.to(DEV)
+            sad = sa.to(DEV).requires_grad_(True)
+            _op()(qd, kd, vd, num_sink=0, window_size=W, s_aux=sad).backward(dod)
+            assert ("dkdvasmskew" in _path()) == (mode == "rule"), _path()
+            res.setdefault(mode, []).append((qd.grad.clone(), kd.grad.clone(), vd.grad.clone()))
+    finally:
+        set_backward_options(overlap=prev[0], dkdv=prev[1] or "rule")
+    a, b = res["rule"]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))                      # deterministic
+    tol = 5e-2
+    assert_close(a[0], dq_r, tol, tol, "dq")
+    assert_close(a[1], dk_r, tol * max(1.0, dk_r.abs().max().item()), tol, "dk")
+    assert_close(a[2], dv_r, tol * max(1.0, dv_r.abs().max().item()), tol, "dv")
+    # ... and no further from the oracle than the compiled kernel of the same call
+    c = res["ws"][0]
+    assert maxdiff(a[1], dk_r) <= 1.5 * maxdiff(c[1], dk_r) + 1e-3 and maxdiff(a[2], dv_r) <= 1.5 * maxdiff(c[2], dv_r) + 1e-3
 
 
 def test_very_long_sequence_and_chunked_tail():

@@ -95,7 +95,7 @@ def test_fewer_queries_than_keys_fwd_bwd(dtype, Hq, Hkv, D, Nq, Nk, ns, W, dkdv)
     out = _sink_flash_attention_ex(qd, kd, vd, ns, W, s_aux=sad)
     assert out.shape == (B, Hq, Nq, D) and "mfma" in _native.last_path()
     out.backward(do.to(DEV))
-    want = dkdv_kernel_name(dkdv, B, Hkv, Nq, Nk, D, W)
+    want = dkdv_kernel_name(dkdv, B, Hkv, Nq, Nk, D, W, ns=ns)
     assert want in _native.last_path(), (want, _native.last_path())
     o_r, _ = O.sink_attention_dense(q, k, v, ns, W, sa)
     dq_r, dk_r, dv_r, dsa_r = O.sink_attention_bwd_dense(q, k, v, do, ns, W, sa)

@@ -73,7 +73,7 @@ def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu, dkdv):
     assert _native.last_path().startswith("fwd_mfma")
     out.backward(do.to(DEV))
     longest = max(b - a for a, b in zip(cu[:-1], cu[1:]))
-    want = dkdv_kernel_name(dkdv, len(cu) - 1, Hkv, longest, longest, D, W, packed=True)
+    want = dkdv_kernel_name(dkdv, len(cu) - 1, Hkv, longest, longest, D, W, packed=True, ns=ns)
     assert want in _native.last_path(), (want, _native.last_path())
     o_r, dq_r, dk_r, dv_r, dsa_r = _per_seq_oracle(q, k, v, do, cu, ns, W, sa)
     assert maxdiff(out, o_r) < 2e-2

@@ -51,14 +51,18 @@ def assert_close(actual, expected, atol, rtol, what=""):
                            f"(atol={atol}, rtol={rtol}); max abs err {err.max().item():.3e}")
 
 
-def dkdv_kernel_name(mode, B, Hkv, Nq, Nk, D, window, packed=False, dtype=torch.bfloat16):
+def dkdv_kernel_name(mode, B, Hkv, Nq, Nk, D, window, packed=False, dtype=torch.bfloat16, ns=1):
     """Name of the dK/dV kernel sfa_bwd must dispatch to, as it appears in sfa_last_path(): restates dkdv_asm() of
     csrc/sfa_bwd_mfma.hip.  mode: "rule" (the library's rule) / "asm" / "ws" (the per-call overrides).  None where the
-    choice does not exist (fp32, head dims without a hand-placed body).  Packed batches: B = sequences, Nq = Nk = the
+    choice does not exist (fp32, head dims without a hand-placed body).  ns = num_sink of the call.  Packed batches: B = sequences, Nq = Nk = the
     longest one (the launch problem of sfa_bwd_varlen)."""
     if dtype == torch.float32 or D not in (64, 80, 96, 128):
         return None
     W = min(max(window, 0), Nk)
+    # short windows without sink keys, self-attention, head dims below 128: the skewed sweep (dkdv_skew() of the library),
+    # unless the call names one of the other kernels
+    if mode == "rule" and D in (64, 80, 96) and ns <= 0 and (packed or Nq == Nk) and 1 <= W <= 512:
+        return "dkdvasmskew"
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     wgs = -(-Nk // 256) * Hkv * B
     if not (D == 128 or W > 256 or wgs >= 2 * n_cu):   # short windows below head dim 128 on a grid that does not fill the chip twice: compiled kernels only

@@ -221,6 +221,7 @@ class Prog:
     def s_add_u32(self, d, a, b, note=""): return self._salu2("s_add_u32", d, a, b, note=note)
     def s_addc_u32(self, d, a, b, note=""): return self._salu2("s_addc_u32", d, a, b, note=note, reads_scc=True)
     def s_sub_u32(self, d, a, b, note=""): return self._salu2("s_sub_u32", d, a, b, note=note)
+    def s_subb_u32(self, d, a, b, note=""): return self._salu2("s_subb_u32", d, a, b, note=note, reads_scc=True)
     def s_add_i32(self, d, a, b, note=""): return self._salu2("s_add_i32", d, a, b, note=note)
     def s_sub_i32(self, d, a, b, note=""): return self._salu2("s_sub_i32", d, a, b, note=note)
     def s_mul_i32(self, d, a, b, note=""): return self._salu2("s_mul_i32", d, a, b, scc=False, note=note)

@@ -69,6 +69,7 @@ class DkdvGen:
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype = dtype
         self.do_sched = sched
+        self.partials = True            # the f32 second epilogue of split sweeps
         # head dim: DK k-steps of 16 in the d contractions, DB 32-wide output blocks of dK^T / dV^T, NCH valid 16-byte
         # chunks per row.  The LDS images keep 256-byte rows for every head dim; chunks >= NCH are fetched through
         # out-of-range offsets (zeros) when a 128-byte half holds some valid chunks, halves with none are not fetched.
@@ -685,6 +686,9 @@ class DkdvGen:
         # 4 D bytes at p?_lo (moved back by the block's first key: the key index is absolute); bwd_part_reduce_kernel adds the
         # chunks up and rounds ONCE.  The accumulator layout gives every lane four consecutive columns per register quad:
         # registers 4 g .. 4 g + 3 of block (db, kbi) = columns 32 db + 8 g + 4 h ... + 3 of the lane's key.
+        if not self.partials:
+            p.s_waitcnt(vmcnt=0)
+            return p
         p.s_cmp("eq_u32", P("p_rng"), 0)
         p.s_cbranch("scc1", "L_nopart%=")
         p.v_mul_u32_u24(self.vo_k[0], 4 * self.D, t2)

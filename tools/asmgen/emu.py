@@ -373,6 +373,8 @@ class Workgroup:
             r = s[0] + s[1] + w.scc; w.scc = int(r > M); self.wr_s(w, ins.dst[0], r); return
         if op == "s_sub_u32":
             r = s[0] - s[1]; w.scc = int(s[1] > s[0]); self.wr_s(w, ins.dst[0], r); return
+        if op == "s_subb_u32":
+            r = s[0] - s[1] - w.scc; w.scc = int(s[1] + w.scc > s[0]); self.wr_s(w, ins.dst[0], r); return
         if op == "s_add_i32":
             r = sg(s[0]) + sg(s[1]); w.scc = int(not (-(1 << 31) <= r < (1 << 31))); self.wr_s(w, ins.dst[0], r); return
         if op == "s_sub_i32":

@@ -409,3 +409,57 @@ def run_dq_strip(prog, q, k, v, do, lse, delta, window, dtype="bf16", NT=3, stri
     raw = mem.read(adq).view(np.uint16).reshape(B, Hq, N, D)
     t = torch.from_numpy(raw.view(np.int16).copy())
     return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+
+
+# ------------------------------------------------------------------------------------------------ skewed dK/dV kernel
+def run_dkdv_skew(prog, q, k, v, do, lse, delta, window, dtype="bf16", check_races=True, blocks=None, stats=None):
+    """the short-window body of dkdv_skew.py (no sink keys, N_q = N_kv): q, do [B, Hq, N, D]; k, v [B, Hkv, N, D];
+    lse, delta [B, Hq, N] float.  Returns dk, dv [B, Hkv, N, D] float32 (the 16-bit values the kernel stored)."""
+    from . import dkdv_skew as KS
+    B, Hq, N, D = q.shape
+    Hkv = k.shape[1]
+    assert k.shape[2] == N
+    g = Hq // Hkv
+    scale = 1.0 / math.sqrt(D)
+    mem = Memory()
+    aq, ak, av, ado = (mem.alloc(to_u16(t)) for t in (q, k, v, do))
+    consts = torch.stack([-(lse.double() / scale), -delta.double()], dim=2).float().contiguous()   # [B, Hq, 2, N]
+    ac = mem.alloc(consts.numpy())
+    adk = mem.alloc_zero(B * Hkv * N * D * 2)
+    adv = mem.alloc_zero(B * Hkv * N * D * 2)
+    W = min(max(window, 0), N)
+    T = max(KS.SKEW, (62 + W) // 32 + 1)
+    for b in range(B):
+        for hk in range(Hkv):
+            for kb in range((N + 255) // 256):
+                if blocks is not None and (b, hk, kb) not in blocks:
+                    continue
+                head0 = hk * g
+                qb = aq + ((b * Hq + head0) * N) * D * 2
+                dob = ado + ((b * Hq + head0) * N) * D * 2
+                cb = ac + ((b * Hq + head0) * 2 * N) * 4
+                kbp = ak + ((b * Hkv + hk) * N) * D * 2
+                vbp = av + ((b * Hkv + hk) * N) * D * 2
+                dkb = adk + ((b * Hkv + hk) * N) * D * 2
+                dvb = adv + ((b * Hkv + hk) * N) * D * 2
+                rng = N * D * 2
+                params = dict(
+                    q_lo=qb & 0xFFFFFFFF, q_hi=qb >> 32, do_lo=dob & 0xFFFFFFFF, do_hi=dob >> 32,
+                    c_lo=cb & 0xFFFFFFFF, c_hi=cb >> 32, k_lo=kbp & 0xFFFFFFFF, k_hi=kbp >> 32,
+                    v_lo=vbp & 0xFFFFFFFF, v_hi=vbp >> 32, dk_lo=dkb & 0xFFFFFFFF, dk_hi=dkb >> 32,
+                    dv_lo=dvb & 0xFFFFFFFF, dv_hi=dvb >> 32,
+                    q_rng=rng, do_rng=rng, c_rng=2 * N * 4, k_rng=rng, v_rng=rng, dk_rng=rng, dv_rng=rng,
+                    q_sn=D * 2, do_sn=D * 2, k_sn=D * 2, v_sn=D * 2, dk_sn=D * 2, dv_sn=D * 2,
+                    q_hs=N * D * 2, do_hs=N * D * 2, c_hs=2 * N * 4,
+                    nq=T, g=g, q_row0=kb * 256, kb0=kb * 256, W=W, nrows=N,
+                    cdelta=N * 4, c_log2=f32_bits(scale * math.log2(math.e)), scale=f32_bits(scale))
+                assert set(params) == set(KS.PARAMS), set(params) ^ set(KS.PARAMS)
+                wg = Workgroup(prog, 4, mem, params, lds_bytes=160 * 1024, check_races=check_races)
+                wg.run()
+                if stats is not None:
+                    stats.append({"block": (b, hk, kb), "icount": [w.icount for w in wg.waves], "kinds": dict(wg.waves[0].stats)})
+    def back(addr):
+        raw = mem.read(addr).view(np.uint16).reshape(B, Hkv, N, D)
+        t = torch.from_numpy(raw.view(np.int16).copy())
+        return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16).float()
+    return back(adk), back(adv)
