@@ -58,49 +58,79 @@ __device__ __forceinline__ void cvt16B(const u32x4& raw, float (&f)[EPL]) {
 // in place, no linearisation copy).
 // Fold the split partials of one (b, h) and the s_aux virtual split (decode_kernel.py:205-226); `nthr` threads
 // starting at `tid` = 0 cooperate (D <= 4 * nthr).
-template <typename T>
+// COH (one-pass mode): the partials were written by workgroups on OTHER XCDs in this same launch.  They are stored and
+// fetched as relaxed agent-scope atomics - `sc1` stores that write through the XCD's L2 and `sc1` loads that do not hit
+// its non-coherent lines - so that no agent-scope FENCE (an L2 write-back + invalidate per workgroup) is needed around
+// the arrival counter.
+template <bool COH>
+__device__ __forceinline__ float ld_part(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+__device__ __forceinline__ void st_part(float* p, float v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// W = lanes that share the split statistics by shuffles (64: a whole wave per head; 32: a half-wave per head, two heads per
+// wave, head dims up to 128).
+template <typename T, bool COH = false, int W = 64>
 __device__ __forceinline__ void reduce_head(const float* __restrict__ Mp, const float* __restrict__ Lp,
                                             const float* __restrict__ Op, const float* __restrict__ s_aux, const View& o,
                                             int Hq, int S, int D, int b, int h, int tid, int nthr) {
-    // Latency-bound: the split statistics are fetched by all lanes at once (lane = split) and folded with wave
-    // reductions; the O rows are then accumulated with 8 independent loads in flight per thread.
+    // Latency-bound (in one-pass mode every load is a round trip to the memory side): the statistics of the first W splits
+    // (lane = split) and the O rows of the first U splits are requested TOGETHER, the weights of those splits come from the
+    // statistics registers by shuffles; further splits (S > W or S > U) take more rounds of U independent loads per thread.
     const int64_t base = ((int64_t)b * Hq + h) * S;
-    const int wl = tid & 63;
-    const float sa = s_aux ? s_aux[h] : -INFINITY;
-    float mloc = -INFINITY;
-    for (int s0 = 0; s0 < S; s0 += 64) {
-        const int s = s0 + wl;
-        if (s < S) mloc = fmaxf(mloc, Mp[base + s]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
-    const float mstar = fmaxf(mloc, sa);
-    float lloc = 0.f;
-    for (int s0 = 0; s0 < S; s0 += 64) {
-        const int s = s0 + wl;
-        if (s < S) {
-            const float ms = Mp[base + s];
-            lloc += Lp[base + s] * ((ms == -INFINITY) ? 0.f : __expf(ms - mstar));
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lloc += __shfl_xor(lloc, off, 64);
-    float L = lloc + ((sa == -INFINITY) ? 0.f : __expf(sa - mstar));
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int wl = tid & (W - 1);
     constexpr int U = 8;
-    for (int s0 = 0; s0 < S; s0 += U) {
-        float w[U], x[U][4];
+    const float sa = s_aux ? s_aux[h] : -INFINITY;
+    const float m0 = wl < S ? ld_part<COH>(Mp + base + wl) : -INFINITY;
+    const float l0 = wl < S ? ld_part<COH>(Lp + base + wl) : 0.f;
+    float x[U][4];
+    auto fetch = [&](int s0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = s0 + u < S ? s0 + u : S - 1;
-            const float ms = Mp[base + s];
-            w[u] = (s0 + u < S && ms != -INFINITY) ? __expf(ms - mstar) : 0.f;
             const float* op = Op + (base + s) * D;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int d = tid + nthr * t;
-                x[u][t] = d < D ? op[d] : 0.f;
+                x[u][t] = d < D ? ld_part<COH>(op + d) : 0.f;
             }
+        }
+    };
+    fetch(0);
+    float mloc = m0;
+    for (int s0 = W; s0 < S; s0 += W) {
+        const int s = s0 + wl;
+        if (s < S) mloc = fmaxf(mloc, ld_part<COH>(Mp + base + s));
+    }
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+    const float mstar = fmaxf(mloc, sa);
+    float lloc = l0 * ((m0 == -INFINITY) ? 0.f : __expf(m0 - mstar));
+    for (int s0 = W; s0 < S; s0 += W) {
+        const int s = s0 + wl;
+        if (s < S) {
+            const float ms = ld_part<COH>(Mp + base + s);
+            lloc += ld_part<COH>(Lp + base + s) * ((ms == -INFINITY) ? 0.f : __expf(ms - mstar));
+        }
+    }
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) lloc += __shfl_xor(lloc, off, 64);
+    float L = lloc + ((sa == -INFINITY) ? 0.f : __expf(sa - mstar));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += U) {
+        if (s0 > 0) fetch(s0);
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u;
+            float ms = -INFINITY;
+            if (s < W) ms = __shfl(m0, s, W);                       // (lanes >= S hold -inf)
+            else if (s < S) ms = ld_part<COH>(Mp + base + s);
+            w[u] = (ms != -INFINITY) ? __expf(ms - mstar) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -305,13 +335,14 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
                 }
                 const int h = hk * g + h0 + t;
                 const int64_t pidx = ((int64_t)b * Hq + h) * S + split;
+                const bool coh = op1.cnt != nullptr;
                 if (chunk == 0) {
-                    Mp[pidx] = mn;
-                    Lp[pidx] = lt;
+                    st_part(Mp + pidx, mn, coh);
+                    st_part(Lp + pidx, lt, coh);
                 }
                 if (dact) {
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) Op[pidx * D + chunk * EPL + e] = o[e];
+                    for (int e = 0; e < EPL; ++e) st_part(Op + pidx * D + chunk * EPL + e, o[e], coh);
                 }
             }
         }
@@ -319,20 +350,29 @@ __global__ __launch_bounds__(256) void decode_split_kernel(View q, View k, View 
     }
     if (op1.cnt) {
         __shared__ int last_flag[2];
-        __threadfence();                                   // this workgroup's partials are visible device-wide
+        // this workgroup's partials went out as write-through (sc1) stores: once they are acknowledged they are visible to
+        // every XCD, no L2 write-back needed (round 2 had __threadfence() on both sides of the counter: every workgroup
+        // flushed and invalidated its XCD's L2, which cost more than the second launch it saved)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (threadIdx.x == 0) {
-            const int old = atomicAdd(&op1.cnt[b * Hkv + hk], 1);
+            const int old = __hip_atomic_fetch_add(&op1.cnt[b * Hkv + hk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last_flag[0] = old == S - 1;
-            if (old == S - 1) op1.cnt[b * Hkv + hk] = 0;   // leave the counter zero for the next call
+            if (old == S - 1) __hip_atomic_store(&op1.cnt[b * Hkv + hk], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next call
             const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
-            const int oldg = atomicAdd(&op1.cnt[gridDim.z * Hkv], 1);
+            const int oldg = __hip_atomic_fetch_add(&op1.cnt[gridDim.z * Hkv], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last_flag[1] = oldg == total - 1;
-            if (oldg == total - 1) op1.cnt[gridDim.z * Hkv] = 0;
+            if (oldg == total - 1) __hip_atomic_store(&op1.cnt[gridDim.z * Hkv], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (last_flag[0]) {
-            __threadfence();                               // acquire: the other splits' partials
-            for (int hh = wave; hh < g; hh += 4) reduce_head<T>(Mp, Lp, Op, op1.s_aux, op1.o, Hq, S, D, b, hk * g + hh, lane, 64);
+            // (the partials are fetched with sc1 loads: they cannot hit stale lines of this XCD's L2)
+            if (D <= 128 && g > 4) {       // two heads per wave (a half-wave covers 32 x 4 columns): the group in one round up to 8 heads
+                for (int hh = wave * 2 + (lane >> 5); hh < g; hh += 8)
+                    reduce_head<T, true, 32>(Mp, Lp, Op, op1.s_aux, op1.o, Hq, S, D, b, hk * g + hh, lane & 31, 32);
+            } else {
+                for (int hh = wave; hh < g; hh += 4) reduce_head<T, true, 64>(Mp, Lp, Op, op1.s_aux, op1.o, Hq, S, D, b, hk * g + hh, lane, 64);
+            }
         }
         if (last_flag[1] && fr.dyn && threadIdx.x == 0) {  // every workgroup has read the state: advance it
             const int wl = fr.dyn[1], wp = fr.dyn[2];

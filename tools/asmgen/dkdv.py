@@ -602,24 +602,28 @@ class DkdvGen:
         p.s_and_b32(self.s_cstn, t0, 1023)
         p.s_add_u32(t0, self.s_cstd, 256)
         p.s_and_b32(self.s_cstd, t0, 1023)
-        if self.ablate:
-            # knock-out builds for tools/ab.py (what does a trip cost without ...): "dma" the LDS-DMA pieces, "exp" the
-            # v_exp, "valu" all VALU of the softmax / dS part, "vfrag" the V fragment reads, "consts" the row constants,
-            # "tr" the transposed reads, "mfma_s" the S / dP chains, "mfma_acc" the dV / dK MFMAs
-            drop = []
-            for it in p.items:
-                k = it.kind
-                if "dma" in self.ablate and k == "dma": drop.append(it)
-                if "exp" in self.ablate and k == "trans": drop.append(it)
-                if "valu" in self.ablate and (k == "trans" or it.op.startswith(("v_mul_f32", "v_cvt_pk"))): drop.append(it)
-                if "vfrag" in self.ablate and k == "ds_read" and "v_img_r" in it.mem_r: drop.append(it)
-                if "consts" in self.ablate and k == "ds_read" and it.src[0] in (self.a_c, self.a_cn): drop.append(it)
-                if "tr" in self.ablate and it.op == "ds_read_b64_tr_b16": drop.append(it)
-                if "mfma_s" in self.ablate and k == "mfma" and it.tag in ("S", "dP"): drop.append(it)
-                if "mfma_acc" in self.ablate and k == "mfma" and it.tag in ("dV", "dK"): drop.append(it)
-            ids = set(id(x) for x in drop)
-            p.items = [it for it in p.items if id(it) not in ids]
+        self.apply_ablate(p)
         return p
+
+    def apply_ablate(self, p: Prog):
+        """knock-out builds for tools/ab.py (what does a trip cost without ...; wrong results, timing only): "dma" the LDS-DMA
+        pieces, "exp" the v_exp, "valu" all VALU of the softmax / dS part, "vfrag" the V fragment reads, "consts" the row
+        constants, "tr" the transposed reads, "mfma_s" the S / dP chains, "mfma_acc" the dV / dK MFMAs"""
+        if not self.ablate:
+            return
+        drop = []
+        for it in p.items:
+            k = it.kind
+            if "dma" in self.ablate and k == "dma": drop.append(it)
+            if "exp" in self.ablate and k == "trans": drop.append(it)
+            if "valu" in self.ablate and (k == "trans" or it.op.startswith(("v_mul_f32", "v_cvt_pk"))): drop.append(it)
+            if "vfrag" in self.ablate and k == "ds_read" and "v_img_r" in it.mem_r: drop.append(it)
+            if "consts" in self.ablate and k == "ds_read" and it.src[0] in (self.a_c, self.a_cn): drop.append(it)
+            if "tr" in self.ablate and it.op == "ds_read_b64_tr_b16": drop.append(it)
+            if "mfma_s" in self.ablate and k == "mfma" and it.tag in ("S", "dP"): drop.append(it)
+            if "mfma_acc" in self.ablate and k == "mfma" and it.tag in ("dV", "dK"): drop.append(it)
+        ids = set(id(x) for x in drop)
+        p.items = [it for it in p.items if id(it) not in ids]
 
     # ------------------------------------------------------------------ epilogue
     def epilogue(self) -> Prog:

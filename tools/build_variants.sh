@@ -1,16 +1,15 @@
 #!/bin/bash
-# Several A/B libraries side by side (one ALT body each): tools/build_variants.sh name1 'json1' name2 'json2' ...
-# -> sink-flash-attention-kernel_amd/sink_attention/libsfa_<name>.so ; run with SFA_LIB_PATH=... python tools/ab.py
+# development: libsfa.so variants whose short-window dK/dV bodies are generated with other parameters (knock-outs, scheduler
+# knobs), for same-box comparisons through SFA_LIB_PATH (tools/kbench.py).  usage: tools/build_variants.sh name='{"json"}' ...
 set -e
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd $(dirname $0)/.. && pwd)
 P=$R/sink-flash-attention-kernel_amd
-while [ $# -ge 2 ]; do
-  name=$1; json=$2; shift 2
-  rm -f $P/csrc/gen/*.inc $P/build/sfa_bwd_mfma.o $P/build/sfa_fwd_mfma.o
-  ASMGEN_ALT="${ASMGEN_ALT_KIND_DKDV:+$json}" ASMGEN_ALT_DQ="${ASMGEN_ALT_KIND_DQ:+$json}" ASMGEN_ALT_FWD="${ASMGEN_ALT_KIND_FWD:+$json}" \
-    make -C $P -j8 EXTRA=-DSFA_AB 2>&1 | grep -E "error|Error" || true
-  cp $P/sink_attention/libsfa.so $P/sink_attention/libsfa_$name.so
-  echo "built libsfa_$name.so ($json)"
+mkdir -p $P/build_ab
+for spec in "$@"; do
+  name=${spec%%=*}; js=${spec#*=}
+  ASMGEN_ALT_SKEW="$js" make -C $P > /tmp/build_$name.log 2>&1 || { tail -5 /tmp/build_$name.log; exit 1; }
+  cp $P/sink_attention/libsfa.so $P/build_ab/libsfa_$name.so
+  echo "built $name"
 done
-rm -f $P/csrc/gen/*.inc $P/build/sfa_bwd_mfma.o $P/build/sfa_fwd_mfma.o
-make -C $P -j8 2>&1 | grep -E "error|Error" || true
+ASMGEN_ALT_SKEW= make -C $P > /tmp/build_base.log 2>&1
+echo "rebuilt the shipped library"

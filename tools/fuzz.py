@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised cross-check on the GPU: MFMA kernels against the exact-f32 kernels of the same library (and the
 N_q < N_kv / packed paths against their padded / per-sequence formulations) on random shapes.
-usage: python tools/fuzz.py [n_cases] [seed]"""
+usage: python tools/fuzz.py [n_cases] [seed] [skew]      (skew: only shapes of the short-window dK/dV kernel - no sink keys,
+head dims 64 / 80 / 96, windows up to 512, N_q = N_kv or packed)"""
 import os
 import random
 import sys
@@ -16,6 +17,7 @@ from sink_attention.varlen import sink_flash_attention_varlen
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 torch.manual_seed(rng.randrange(1 << 30))
+focus_skew = len(sys.argv) > 3 and sys.argv[3] == "skew"
 bad = 0
 
 
@@ -39,6 +41,9 @@ for case in range(n_cases):
     dt = rng.choice([torch.bfloat16, torch.float16])
     aux = rng.random() < 0.6
     mode = rng.choice(["plain", "plain", "offset", "varlen"])
+    if focus_skew:
+        D, ns, W = rng.choice([64, 80, 96]), 0, rng.choice([1, 5, 31, 64, 100, 128, 300, 512])
+        mode = rng.choice(["plain", "plain", "varlen"])
     sa = (torch.randn(Hq, device="cuda") * 0.5) if aux else None
     tol_o, tol_g = (2e-2, 2e-1) if dt == torch.bfloat16 else (5e-3, 6e-2)
     desc = f"{mode} B{B} Hq{Hq} Hkv{Hkv} N{N} D{D} ns{ns} W{W} {str(dt)[6:]} aux{int(aux)}"

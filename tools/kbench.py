@@ -100,7 +100,8 @@ def main():
                   f"{f / med / 1e9:8.1f} TFLOP/s ({f / med / 1e9 / 2516.6 * 100:5.1f}% peak)", flush=True)
     if "decode" in args.what:
         for (B, Hq, Hkv, Nkv, D) in [(32, 32, 32, 131072, 128), (32, 32, 32, 4100, 128), (32, 32, 8, 131072, 128),
-                                     (1, 32, 8, 4100, 128), (1, 64, 8, 4100, 128)]:
+                                     (1, 32, 8, 4100, 128), (1, 64, 8, 4100, 128), (4, 64, 8, 4100, 128), (16, 64, 8, 4100, 128),
+                                     (1, 64, 8, 4100, 64), (1, 32, 8, 132, 128)]:
             q = torch.randn(B, Hq, 1, D, device=dev, dtype=dt)
             k = torch.randn(B, Hkv, Nkv, D, device=dev, dtype=dt)
             v = torch.randn(B, Hkv, Nkv, D, device=dev, dtype=dt)
@@ -108,7 +109,22 @@ def main():
             byts = 2 * k.numel() * 2 + 2 * q.numel() * 2
             print(f"decode B{B} Hq{Hq} Hkv{Hkv} N{Nkv} {_native.last_path():28s} med {med:8.4f} ms min {mn:8.4f} ms "
                   f"{byts / med / 1e6:8.1f} GB/s ({byts / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
-            del q, k, v
+            # the raw C call with a caller-owned workspace: two launches, and SFA_FLAG_DECODE_ONE_PASS (one launch)
+            lib = _native.lib()
+            out = torch.empty_like(q)
+            nb = int(lib.sfa_decode_workspace_bytes(B, Hq, Hkv, Nkv, D, _native.SFA_DTYPE[q.dtype]))
+            ws = torch.zeros(max(nb, 256), device=dev, dtype=torch.uint8)
+            for flag, nm in ((0, "raw 2 launches"), (_native.FLAG_DECODE_ONE_PASS, "raw one pass")):
+                def call():
+                    st = lib.sfa_decode(_native.desc(q), _native.desc(k), _native.desc(v), _native.desc(out), None, ws.data_ptr(),
+                                        ws.numel(), 1.0 / D ** 0.5, flag, _native.stream_ptr(q.device))
+                    assert st == 0
+                ref = sink_decode_attention(q, k, v)
+                call()
+                err = (out.float() - ref.float()).abs().max().item()
+                med, mn = timeit(call, args.iters)
+                print(f"   {nm:16s} {_native.last_path():34s} med {med:8.4f} ms min {mn:8.4f} ms  max|diff| {err:.2e}", flush=True)
+            del q, k, v, ws
 
 
 if __name__ == "__main__":
