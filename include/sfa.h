@@ -63,8 +63,9 @@ extern "C" {
  * break-even against 7 GB of workspace, removed).  The bit is accepted and ignored. */
 /* sfa_decode*: one launch instead of two.  The last KV split of a (batch, KV head) to finish folds the split partials
  * itself (atomic arrival counters).  Contract: the caller OWNS the workspace across calls and zero-initialised its FIRST
- * align256((B * Hkv + 1) * 4) bytes once; the kernel leaves them zero.  Worth it at small batch, where a decode step is
- * two ~10 us launches otherwise. */
+ * align256((B * Hkv + 1) * 4) bytes once; the kernel leaves them zero.  No agent-scope fence is involved (the partials are
+ * written through and fetched past the per-XCD L2s, the counters are relaxed atomics).  Measured: a gain only where the cache
+ * is short enough for ONE split (B = 1, 132 keys: 15.8 vs 19.2 us); at 4100 keys two launches are 2 us faster. */
 #define SFA_FLAG_DECODE_ONE_PASS 0x4u
 /* sfa_bwd / sfa_bwd_varlen: the dQ and dK/dV kernels are independent; on a SMALL grid (dQ grid below 4 workgroups per
  * CU: batch 1, tensor- or sequence-parallel shards) the dQ kernel is launched on a library-owned side stream of the

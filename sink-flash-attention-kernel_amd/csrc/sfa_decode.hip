@@ -147,9 +147,9 @@ __device__ __forceinline__ void reduce_head(const float* __restrict__ Mp, const 
 }
 
 // One-pass mode (SFA_FLAG_DECODE_ONE_PASS): `cnt` = zero-initialised int32 [B * Hkv + 1] counters that the kernel
-// leaves zero.  The LAST split of a (b, KV head) to arrive (atomic counter, fences on both sides) folds the partials of
-// that head group itself, so there is no second launch; the last workgroup of the whole grid advances the device
-// state.  At B = 1 a decode step is two ~10 us launches otherwise.
+// leaves zero.  The LAST split of a (b, KV head) to arrive (relaxed atomic counter; the partials travel as write-through
+// stores / sc1 loads, see ld_part) folds the partials of that head group itself, so there is no second launch; the last
+// workgroup of the whole grid advances the device state.
 struct OnePass {
     int* cnt;
     const float* s_aux;

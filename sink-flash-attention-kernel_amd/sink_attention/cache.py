@@ -175,8 +175,9 @@ class SinkCacheLayer(_HFLayer if _HAS_HF else object):
     one_pass = False     # opt-in: SFA_FLAG_DECODE_ONE_PASS (last-arriver fold inside the split kernel, one launch)
 
     def _decode_flags(self, N) -> int:
-        # Measured on MI355X at B=1: 18 vs 21 us per step at W=1024 but 28-38 vs 22-28 us at W=4096 - the agent-scope
-        # fences around the arrival counter write back / invalidate the per-XCD L2s - so two launches stay the default.
+        # Measured on MI355X (round 3, fence-free fold: write-through partial stores, sc1 loads; profiles/r03_kbench_decode_1pass.log):
+        # B=1, 4100 keys 21.2 vs 19.2 us with two launches (the fold's loads are round trips to the memory side, dearer than
+        # a back-to-back launch), 132 keys (one split) 15.8 vs 19.2 us - so two launches stay the default.
         return N.FLAG_DECODE_ONE_PASS if self.one_pass else 0
 
     # ------------------------------------------------ device-resident state (hipGraph capture)

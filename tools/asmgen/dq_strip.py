@@ -36,7 +36,8 @@ class DqStripGen(DqGen):
         # The finished item's stores come FIRST (its accumulators must be free when the first tile's dQ MFMAs start), then the
         # next item's loads, its tile's DMA pieces last; everything has landed at the next item's head (vmcnt(0)).
         # (positions are MFMA indices of the item's block)
-        nm = NT * (4 * (D // 16) * 2 + 8 * ((D + 31) // 32))      # MFMAs of the block: S, dP chains + dQ per tile
+        nm = NT * (4 * (D // 16) * 2 + 8 * ((D + 31) // 32))      # MFMAs of the block: S, dP chains + dQ per tile ...
+        nm = nm * (4 * NT - 2) // (4 * NT)                        # ... less two dead sub-blocks per (steady) item, tile_sub()
         self.st_from = st_from if st_from is not None else 2
         self.st_step = st_step if st_step is not None else max(1, int(0.22 * nm / 10))
         self.ld_from = int(0.27 * nm)
@@ -151,9 +152,26 @@ class DqStripGen(DqGen):
         for rb in range(2):
             p.v_add_u32(self.v_lc[rb], 256, self.v_lc[rb])
 
+    def tile_sub(self, j):
+        """sub-block classes of the item's tile j, sub[kh][rb] (key half x row block) in "mask" / "full" / "dead" (fwd_strip.py):
+        the last tile is the diagonal one - rows 0..31 never see its keys 32..63; steady items: rows 32..63 never see the first
+        tile's keys 0..31 and see every one of the diagonal tile's keys 0..31, rows 0..31 every one of the first tile's keys
+        32..63.  A dead sub-block is left out of every phase, a full one gets no mask instructions."""
+        sub = [["mask", "mask"], ["mask", "mask"]]
+        if j == self.NT - 1:
+            sub[1][0] = "dead"
+            if self.steady:
+                sub[0][1] = "full"
+        elif j == 0 and self.steady:
+            sub[0][1] = "dead"
+            sub[1][0] = "full"
+        return sub
+
     def emit_tile(self, p: Prog, buf, j, first):
         """tile j of the current item (ring offset s_slot[j], first key s_k0t[j]); first: dQ^T starts from 0 (srcC = 0)"""
         dt = self.dtype
+        sub = self.tile_sub(j)
+        started = [False, False]
         QF, DOF = self.QFB[buf], self.DOFB[buf]
         lse2, nd = self.lse2b[buf], self.ndb[buf]
         ke, ko, ve, vo_, tr0, tr1 = self.addr[j & 1]
@@ -187,6 +205,8 @@ class DqStripGen(DqGen):
                 p.ds_read_b128(f, ko if ks & 1 else ke, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
                 kf.append(f)
             for rb in range(2):
+                if sub[kh][rb] == "dead":
+                    continue
                 for ks in range(self.DK):
                     p.mfma(dt, self.SACC[kh][rb], kf[ks], QF[rb][ks], self.SACC[kh][rb] if ks else 0, tag="S")
             vf = []
@@ -195,14 +215,18 @@ class DqStripGen(DqGen):
                 p.ds_read_b128(f, vo_ if ks & 1 else ve, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="V rows")
                 vf.append(f)
             for rb in range(2):
+                if sub[kh][rb] == "dead":
+                    continue
                 for ks in range(self.DK):
                     p.mfma(dt, self.DPACC[kh][rb], vf[ks], DOF[rb][ks], self.DPACC[kh][rb] if ks else 0, tag="dP")
             for rb in range(2):
+                if sub[kh][rb] == "dead":
+                    continue
                 for v in range(16):
                     x, y = self.SACC[kh][rb][v], self.DPACC[kh][rb][v]
                     p.v_fma_f32(x, x, P("c_log2"), lse2[rb])
                     p.v_exp_f32(x, x)
-                    if cls:
+                    if cls and sub[kh][rb] != "full":
                         c = 32 * kh + (v & 3) + 8 * (v >> 2)
                         if cls == 1:
                             p.v_sub_u32(self.tmp[0], vdj[rb], c)
@@ -223,8 +247,13 @@ class DqStripGen(DqGen):
                     p.ds_read_b64_tr_b16(f[0:2], tr0, off + 2048 * (2 * s), mem=("stage_r",))
                     p.ds_read_b64_tr_b16(f[2:4], tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
                     for rb in range(2):
-                        zero = first and kh == 0 and s == 0
+                        if sub[kh][rb] == "dead":
+                            continue
+                        zero = first and not started[rb]
                         p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], 0 if zero else self.DQ[rb][db], tag="dQ")
+                for rb in range(2):
+                    if sub[kh][rb] != "dead":
+                        started[rb] = True
 
     def emit_epilogue(self, p: Prog):
         """the finished item: dQ[row, d] = scale dQ^T[d, row], stores; then the offsets move on by one item"""

@@ -192,6 +192,14 @@ class FwdGen(WorkList):
             if deadline is not None:
                 ins.mods["alap"] = deadline + 6 * ks
 
+    # Sub-block classes of a tile (the short-window strip bodies, fwd_strip.py): self.sub = None, or sub[kh][rb] in ("mask",
+    # "full", "dead") for key half kh x row block rb - a "dead" sub-block (no row sees any of its keys) is left out of every
+    # phase, a "full" one (every row sees every key) gets no mask instructions.
+    sub = None
+
+    def sub_is(self, kh, rb, what):
+        return self.sub is not None and self.sub[kh][rb] == what
+
     def emit_A(self, p: Prog, par_next: int, e, o, pre=False):
         """S^T of a tile whose K image row-read addresses are e / o: four chains of 8, into SS[par_next]; pre: pool slots
         0..3 already hold the first four fragments"""
@@ -205,6 +213,8 @@ class FwdGen(WorkList):
                     p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
                 kf.append(f)
             for rb in range(2):
+                if self.sub_is(kh, rb, "dead"):
+                    continue
                 acc = self.SS[par_next][kh][rb]
                 for ks in range(self.DK):
                     p.mfma(dt, acc, kf[ks], self.QF[rb][ks], acc if ks else 0, tag="S")
@@ -224,6 +234,8 @@ class FwdGen(WorkList):
                 if cls == 4:                                            # window only: key valid <=> c > (pos - k0 - 4 h) - W
                     p.v_sub_u32(self.v_d[rb], self.v_d[rb], self.v_w)
                 for kh in range(2):
+                    if self.sub_is(kh, rb, "dead") or self.sub_is(kh, rb, "full"):
+                        continue
                     for v in range(16):
                         x = self.SS[par][kh][rb][v]
                         c = 32 * kh + (v & 3) + 8 * (v >> 2)
@@ -243,16 +255,16 @@ class FwdGen(WorkList):
                             p.v_cmp("lt_u32", t[0], self.v_w)
                         p.v_cndmask(x, self.v_ninf, x)
             # row maximum over the lane's 32 scores (two trees of max3), then across the two half-waves
-            regs = [self.SS[par][kh][rb][v] for kh in range(2) for v in range(16)]
+            regs = [self.SS[par][kh][rb][v] for kh in range(2) if not self.sub_is(kh, rb, "dead") for v in range(16)]
             mx, mx2 = t[2], t[3]
             p.v_max3_f32(mx, regs[0], regs[1], regs[2])
             p.v_max3_f32(mx2, regs[3], regs[4], regs[5])
             i = 6
-            while i + 3 < 32:
+            while i + 3 < len(regs):
                 p.v_max3_f32(mx, mx, regs[i], regs[i + 1])
                 p.v_max3_f32(mx2, mx2, regs[i + 2], regs[i + 3])
                 i += 4
-            p.v_max3_f32(mx, mx, regs[30], regs[31])
+            p.v_max3_f32(mx, mx, regs[-2], regs[-1])
             p.v_max_f32(mx, mx, mx2)
             p.v_mov(mx2, mx)
             p.v_permlane32_swap(mx, mx2, note="lanes 32..63 of mx <-> lanes 0..31 of mx2: each lane now holds both halves")
@@ -287,6 +299,8 @@ class FwdGen(WorkList):
         first (the PV of that half starts while the second half is still being exponentiated)"""
         for kh in range(2):
             for rb in range(2):
+                if self.sub_is(kh, rb, "dead"):
+                    continue
                 acc = self.SS[par][kh][rb]
                 for v in range(16):
                     if "fma" not in self.ablate:
@@ -306,7 +320,7 @@ class FwdGen(WorkList):
             for s in range(2):
                 pf = [self.SS[par][kh][rb][4 * s:4 * s + 4] for rb in range(2)]
                 for rb in range(2):
-                    if not self.lsum_valu:
+                    if not self.lsum_valu and not self.sub_is(kh, rb, "dead"):
                         p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
                 for db in range(self.DB):
                     f = self.pool()
@@ -314,7 +328,8 @@ class FwdGen(WorkList):
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
                     p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
                     for rb in range(2):
-                        p.mfma(dt, self.OACC[rb][db], f, pf[rb], self.OACC[rb][db], tag="PV")
+                        if not self.sub_is(kh, rb, "dead"):
+                            p.mfma(dt, self.OACC[rb][db], f, pf[rb], self.OACC[rb][db], tag="PV")
 
     def emit_next_class(self, p: Prog, it_next):
         """state of the trip that processes tile it_next in E / C: first key and class of the tile after it (the one

@@ -152,18 +152,44 @@ class FwdStripGen(FwdGen):
                 if spread_from is not None:      # (spread: the CU's address path takes ~56 cycles per such load)
                     self.gate(ins, spread_from + self.ld_step * (rb * self.DK + ks))
 
+    def tile_sub(self, j):
+        """sub-block classes (fwd.py: sub[kh][rb]) of the item's tile j.  The LAST tile is the diagonal one for every item (its
+        keys are the item's own 64 positions): rows 0..31 never see keys 32..63 - dead in both block sets (its E / C run in
+        the NEXT item's first block, whatever set that item takes).  Steady items (W = 64 (NT - 1) or one more, every tile
+        exists): rows 32..63 never see the first tile's keys 0..31, and see all of the diagonal tile's keys 0..31; rows 0..31
+        see all of the first tile's keys 32..63."""
+        sub = [["mask", "mask"], ["mask", "mask"]]
+        if j == self.NT - 1:
+            sub[1][0] = "dead"
+            if self.steady:
+                sub[0][1] = "full"
+        elif j == 0 and self.steady:
+            sub[0][1] = "dead"
+            sub[1][0] = "full"
+        else:
+            return None
+        return sub
+
     def emit_A_at(self, p: Prog, par, j, i):
         """S^T of the item's tile j into SS[par]; address register pair i"""
         e, o = self.ak[i]
         p.v_add_u32(e, self.s_slot[j], self.l_row_e)
         p.v_xor(o, 32, e)
+        self.sub = self.tile_sub(j)
         self.emit_A(p, par, e, o)
+        self.sub = None
+
+    def emit_E_at(self, p: Prog, par, j):
+        self.sub = self.tile_sub(j)
+        self.emit_E(p, par)
+        self.sub = None
 
     def emit_M_at(self, p: Prog, par, j):
         """mask / maximum / reference point of tile j in SS[par].  General blocks: the one-compare mask with threshold W, or 0
         for a tile index below 0.  Steady blocks (every tile of the item exists, W = 64 (NT - 1) or one more - the gpt-oss
         window of 128): the last tile is the diagonal one (causal test only), the first lies wholly below the rows (window test
         only; two VALU per element instead of three), the ones between need no mask."""
+        self.sub = self.tile_sub(j)
         if self.steady:
             keep = self.v_w
             self.v_w = self.v_wc
@@ -171,6 +197,7 @@ class FwdStripGen(FwdGen):
             # then wholly inside every row's window and need no mask at all)
             self.emit_M(p, par, 3 if j == self.NT - 1 else (4 if j == 0 else 0), self.s_k0[j])
             self.v_w = keep
+            self.sub = None
             return
         p.s_cmp("lt_i32", self.s_k0[j], 0)
         p.s_cselect(self.s_tmp[4], 0, P("W"))
@@ -179,6 +206,7 @@ class FwdStripGen(FwdGen):
         self.v_w = self.v_wt
         self.emit_M(p, par, 1, self.s_k0[j])
         self.v_w = keep
+        self.sub = None
 
     def emit_C_at(self, p: Prog, par, j, first):
         """O^T += V^T P^T, l += 1 P^T for tile j in SS[par]; first: the item's first tile - O starts from 0 (srcC = 0, the
@@ -191,19 +219,28 @@ class FwdStripGen(FwdGen):
                 p.v_mul_f32(self.tmp[rb], P("l0"), self.alpha[rb])
                 for i in range(16):
                     p.v_accvgpr_write(self.LACC[rb][i], self.tmp[rb])
+        sub = self.tile_sub(j)
+        dead = lambda kh, rb: sub is not None and sub[kh][rb] == "dead"
+        started = [False, False]          # the row block's first PV MFMA of the item starts O from 0
         for kh in range(2):
             for s in range(2):
                 pf = [self.SS[par][kh][rb][4 * s:4 * s + 4] for rb in range(2)]
                 for rb in range(2):
-                    p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
+                    if not dead(kh, rb):
+                        p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
                 for db in range(self.DB):
                     f = self.pool()
                     off = 16384 + 8192 * kh + 512 * db
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
                     p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
                     for rb in range(2):
-                        zero = first and kh == 0 and s == 0
+                        if dead(kh, rb):
+                            continue
+                        zero = first and not started[rb]
                         p.mfma(dt, self.OACC[rb][db], f, pf[rb], 0 if zero else self.OACC[rb][db], tag="PV")
+                for rb in range(2):
+                    if not dead(kh, rb):
+                        started[rb] = True
 
     def emit_epilogue(self, p: Prog):
         """the finished item: O = O^T / l (l = 0 -> 1), LSE = ln2 (m + log2 l), stores; m of the finished item is read HERE,
@@ -414,7 +451,7 @@ class FwdStripGen(FwdGen):
         self.QF = self.QFB[buf]
         last = (NT - 1) & 1
         if not head:
-            self.emit_E(p, last)                              # previous item's last tile (its slot offsets are still in s_slot)
+            self.emit_E_at(p, last, NT - 1)                   # previous item's last tile (its slot offsets are still in s_slot)
             self.emit_C_at(p, last, NT - 1, first=False)
             # the new item: tile window + 1, ring offset + 1 slot, rows + 64
             self.emit_advance(p)
@@ -431,8 +468,9 @@ class FwdStripGen(FwdGen):
         # positions (MFMA indices of the BIG block: 8 DB + 8 of the previous item's last PV, 8 DK of A(t0), 8 DK of A(t1), then
         # C(t0)): the finished item's stores and the next item's loads interleave between the end of the previous PV and C(t0)
         # - the stores must be out before C(t0) writes the accumulators - the tile's DMA pieces go under C(t0)
-        n0 = 0 if head else 8 * self.DB + 8
-        n1 = n0 + 16 * self.DK
+        n_sub = lambda j: 4 - sum(x == "dead" for row in (self.tile_sub(j) or []) for x in row)      # live sub-blocks of tile j
+        n0 = 0 if head else (2 * self.DB + 2) * n_sub(NT - 1)
+        n1 = n0 + self.DK * (n_sub(0) + (n_sub(1) if NT >= 2 else 0))
         nld, nst = 2 * self.DK, self.n_store() - 2
         self.ld_step = max(1, (n1 - n0 - 2) // nld)
         self.st_from, self.st_step = (None, 0) if head else (n0 + 2, max(1, (n1 - n0 - 4) // nst))
@@ -446,7 +484,7 @@ class FwdStripGen(FwdGen):
         self.emit_M_at(p, 0, 0)
         if NT >= 2:
             self.emit_A_at(p, 1, 1, 1)
-        self.emit_E(p, 0)
+        self.emit_E_at(p, 0, 0)
         self.emit_C_at(p, 0, 0, first=True)
         if NT >= 2:
             self.emit_M_at(p, 1, 1)
@@ -458,7 +496,7 @@ class FwdStripGen(FwdGen):
         self.pool_next = 0
         self.QF = self.QFB[buf]
         self.emit_A_at(p, j & 1, j, 0)
-        self.emit_E(p, (j - 1) & 1)
+        self.emit_E_at(p, (j - 1) & 1, j - 1)
         self.emit_C_at(p, (j - 1) & 1, j - 1, first=False)
         self.emit_M_at(p, j & 1, j)
         return p
@@ -468,7 +506,7 @@ class FwdStripGen(FwdGen):
         NT = self.NT
         self.pool_next = 0
         last = (NT - 1) & 1
-        self.emit_E(p, last)
+        self.emit_E_at(p, last, NT - 1)
         self.emit_C_at(p, last, NT - 1, first=False)
         self.emit_epilogue(p)
         p.s_waitcnt(vmcnt=0)
