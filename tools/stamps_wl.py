@@ -50,16 +50,17 @@ def main():
     print(_native.last_path())
     if args.phases:
         d = dbg.view(G, 4).cpu().long() & 0xFFFFFFFF
-        d = d[d[:, 3] > 1]
-        nt = (d[:, 3] - 1).float()
+        d = d[(d[:, 3] & 1023) > 1]
+        nt = ((d[:, 3] & 1023) - 1).float()
         a0, a1, a2 = (d[:, i].float() / nt for i in range(3))
         print("per item transition (cycles, mean over %d waves): loop end -> next item's requests issued %.0f | -> finished item's "
               "stores issued %.0f | -> next item's data landed, first K fragments requested %.0f" % (len(d), a0.mean(), a1.mean(), a2.mean()))
         return
     d = dbg.view(G, 4).cpu().long() & 0xFFFFFFFF
-    live = d[:, 3] > 0
+    live = (d[:, 3] & 1023) > 0
     d = d[live]
-    t0, t1, xcc, n = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+    t0, t1, xcc, n = d[:, 0], d[:, 1], d[:, 2], d[:, 3] & 1023
+    cyc = ((d[:, 3] >> 10) << 4).float()         # shader cycles (s_memtime) of the workgroup's life
     start, end = t0.min().item(), t1.max().item()
     span = (end - start) / 100.0
     life = ((t1 - t0) & 0xFFFFFFFF).float() / 100.0
@@ -68,12 +69,13 @@ def main():
     print("workgroups %d  kernel span %.1f us | life: mean %.1f min %.1f max %.1f us | idle at the end: mean %.1f max %.1f us (%.1f %% of the span) | "
           "start skew: mean %.1f max %.1f us" % (len(d), span, life.mean(), life.min(), life.max(), idle.mean(), idle.max(),
                                                100 * idle.mean() / span, late.mean(), late.max()))
+    print("shader clock held during the kernel (cycles / life, mean over the workgroups): %.0f MHz" % (cyc / life).mean().item())
     for x in range(8):
         m = xcc == x
         if m.any():
-            print("  XCC %d: %3d workgroups, items %d..%d, life mean %.1f min %.1f max %.1f us, sum %.0f us, last end %.1f us" % (
+            print("  XCC %d: %3d workgroups, items %d..%d, life mean %.1f min %.1f max %.1f us, sum %.0f us, last end %.1f us, clock %.0f MHz" % (
                 x, int(m.sum()), n[m].min(), n[m].max(), life[m].mean(), life[m].min(), life[m].max(), life[m].sum(),
-                (t1[m].max().item() - start) / 100.0))
+                (t1[m].max().item() - start) / 100.0, (cyc[m] / life[m]).mean().item()))
 
 
 if __name__ == "__main__":
