@@ -8,7 +8,7 @@ swept in T trips; in trip r wave w takes
         slice r of head h                 if r >= 2 w          ("A")
         slice T + r of head h - 1         if r <  2 w          ("B": the tail the wave still owes the previous head)
 so that every slice is consumed in ONE trip by all the waves that need it, a trip consumes exactly two slices (one for r >= 6)
-and the ring stays 4 stages deep: stage = [A image | B image], 32 KB.  Trips per workgroup T (g + 1) instead of (T + 6) g
+and the ring stays 4 stages deep: stage = [A image | B image], 32 KB.  Trips per workgroup T g + 6 instead of (T + 6) g
 (W = 128, g = 8: 54 instead of 96).  The slices of head -1 and head g do not exist: zero-record descriptors, the waves compute
 zeros there.  Head dims below 128 leave accumulator registers free: the V fragments of the wave's keys are pinned there like the
 K fragments (no V image in LDS, no V reads in the trip).
@@ -72,11 +72,15 @@ class DkdvSkewGen(DkdvGen):
     def emit_dma_issue(self, p: Prog, spread: bool = False):
         dl = (lambda i: {"alap": self.dma_t0 + self.dma_dt * i}) if spread else (lambda i: {})
         n = 0
-        # ---- B: slice T + ldq of head ldh - 1, through the scratch descriptor (the head's base one head stride back)
+        # ---- B: slice T + ldq of head ldh - 1, through the scratch descriptor (the head's base one head stride back); no wave
+        #      takes a B slice in trips r >= SKEW (windows above 128: T > SKEW): zero records there as well
+        bm = self.s_tmp[2]
+        p.s_cmp("lt_u32", self.s_ldq, SKEW)
+        p.s_cselect(bm, self.s_bmask, 0)
         for nm, d, vo, img in (("q", self.d_q, self.vo_qb, B_IMG), ("do", self.d_do, self.vo_db, B_IMG + 8192)):
             p.s_sub_u32(self.d_x[0], d[0], P(nm + "_hs"))
             p.s_subb_u32(self.d_x[1], d[1], 0)
-            p.s_and_b32(self.d_x[2], P(nm + "_rng"), self.s_bmask)
+            p.s_and_b32(self.d_x[2], P(nm + "_rng"), bm)
             p.s_add_m0(self.s_std, self.s_wofs)
             if img:
                 p.s_add_m0(M0, img)
@@ -86,7 +90,7 @@ class DkdvSkewGen(DkdvGen):
                 p.buffer_load_lds(16, vo[1], self.d_x, 0, mem=("dma_stage",)).mods.update(dl(n)); n += 1
         p.s_sub_u32(self.d_x[0], self.d_c[0], P("c_hs"))
         p.s_subb_u32(self.d_x[1], self.d_c[1], 0)
-        p.s_and_b32(self.d_x[2], P("c_rng"), self.s_bmask)
+        p.s_and_b32(self.d_x[2], P("c_rng"), bm)
         p.s_sub_i32(self.s_tmp[0], P("nrows"), self.s_ldrow, note="rows left in the sequence behind A's first row")
         p.s_sub_i32(self.s_tmp[1], self.s_tmp[0], self.s_t32)
         p.v_cmp("gt_i32", self.s_tmp[1], self.lane31)
@@ -263,8 +267,9 @@ class DkdvSkewGen(DkdvGen):
         p.s_mov(self.s_ldh, 0)
         p.s_mov(self.s_bmask, 0)
         p.s_mov(self.s_ldrow, P("q_row0"))
-        p.s_add_u32(self.s_n, P("g"), 1)
-        p.s_mul_i32(self.s_n, self.s_n, P("nq"))
+        # trips: T per head, and SKEW more for the tail the waves still owe the last head (B slices exist for r < SKEW only)
+        p.s_mul_i32(self.s_n, P("g"), P("nq"))
+        p.s_add_u32(self.s_n, self.s_n, SKEW)
 
         for acc in (self.DV, self.DKA):
             for db in range(self.DB):
