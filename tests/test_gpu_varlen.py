@@ -54,7 +54,9 @@ def test_varlen_fwd_bwd_matches_per_sequence_oracle(dtype, dkdv):
     (1, 1, 80, 130, 300, [0, 200, 400]),                         # row constants must follow the LAUNCH's kernel choice
     (8, 2, 128, 4, 300, [0, 1100, 1101, 2300, 4400]),            # D = 128, W > 256, sinks, SMALL grid (5 blocks x 2 KV heads x 4
                                                                  # sequences < CUs): the rule takes the compiled kernel, no sink split
-    (16, 16, 128, 4, 600, [0, 4500, 9000])])                     # ... and a pack whose grid fills the chip: hand-placed under the rule too
+    (16, 16, 128, 4, 600, [0, 4500, 9000]),                      # ... and a pack whose grid fills the chip: hand-placed under the rule too
+    (16, 2, 80, 0, 128, [0, 300, 301, 1500, 2100])])             # gpt-oss sliding layer packed: group of 8, no sinks, W = 128 - the skewed
+                                                                 # dK/dV sweep under the rule (sequences of 300 / 1 / 1199 / 600 rows)
 def test_varlen_native_kernels_one_launch(Hq, Hkv, D, ns, W, cu, dkdv):
     """The packed kernels (cu_seqlens inside the grid) against the per-sequence oracle, forward and backward, and
     against the sequence-by-sequence path of the same library."""
