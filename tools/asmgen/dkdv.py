@@ -18,6 +18,11 @@ machine mapping:
   is placed into the gaps by tools/asmgen/sched.py.
   Q / dO slices (and the 64 row constants) arrive by LDS-DMA three slices ahead into a 4-deep ring; one s_barrier per
   trip; the wave's V rows sit in LDS for the whole workgroup, its K fragments in registers.
+  Three trip bodies per wave: "full" (no mask instructions), "edge" (per-element masks) and "dead" - no row of the slice sees
+  any key of the wave (the block's sweep covers the rows that ANY of its 256 keys can see: a wave's 64 keys are out of reach
+  in 6 of them per q head): the wave issues its LDS-DMA pieces, keeps its state and waits at the barrier.  Same results bit
+  for bit; C3 dK/dV -2.9 %, W = 1024 -4 ... -8 %, W = 128 -9 % (in-process A/B, profiles/r03_ab_dkdv_dead.log): the idle
+  waves' MFMAs cost power (the XCDs clock higher without them) and LDS bandwidth.
 
 LDS map (bytes):   [0, 1024)            row constants, 4 stages x (32 x -LSE/scale | 32 x -Delta) f32
                    [1024, 66560)        4 stages x (Q slice image 8 KB | dO slice image 8 KB)
@@ -65,11 +70,14 @@ class Alloc:
 
 
 class DkdvGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125, D=128):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125, D=128, ahead=3, dead=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype = dtype
         self.do_sched = sched
         self.partials = True            # the f32 second epilogue of split sweeps
+        self.dead = dead                # a third trip body for trips in which no row sees any key of the wave: no MFMA, no VALU
+        self.ahead = ahead              # slices the LDS-DMA runs ahead of the trip (3 = what the 4-deep ring allows; 2: experiment)
+        assert ahead in (2, 3)
         # head dim: DK k-steps of 16 in the d contractions, DB 32-wide output blocks of dK^T / dV^T, NCH valid 16-byte
         # chunks per row.  The LDS images keep 256-byte rows for every head dim; chunks >= NCH are fetched through
         # out-of-range offsets (zeros) when a 128-byte half holds some valid chunks, halves with none are not fetched.
@@ -236,7 +244,10 @@ class DkdvGen:
 
     def emit_class(self, p: Prog):
         """s_full = class of (the wave's 64 keys) x (the 32 rows at s_q0p): 1 <=> every key is causal for every row and
-        (all keys are sinks or all are inside every row's window): kw63 <= q0p and (kw63 < ns or kw0 + W > q0p + 31)"""
+        (all keys are sinks or all are inside every row's window): kw63 <= q0p and (kw63 < ns or kw0 + W > q0p + 31);
+        2 (dead=True builds) <=> no row sees any key: every key lies behind every row (kw0 > q0p + 31), or the wave holds no
+        sink key and every key has left every row's window (q0p - kw63 >= W) - the trips a wave spends on slices that only
+        the OTHER waves' keys can see (6 of every sweep in lock step); else 0 (edge: per-element masks)"""
         t0, t1 = self.s_tmp[1], self.s_tmp[2]
         p.s_cmp("le_i32", self.s_kw63, self.s_q0p)
         p.s_cselect(t0, 1, 0)
@@ -245,6 +256,21 @@ class DkdvGen:
         p.s_cselect(t1, 1, 0)
         p.s_or_b32(t1, t1, self.s_allsink)
         p.s_and_b32(self.s_full, t0, t1)
+        if self.dead:
+            t2 = self.s_tmp[0]
+            p.s_add_u32(t1, self.s_q0p, 94)
+            p.s_cmp("gt_i32", self.s_kw63, t1)                  # kw0 = kw63 - 63 > q0p + 31
+            p.s_cselect(t0, 1, 0)
+            p.s_sub_u32(t2, self.s_kw63, 63)
+            p.s_cmp("ge_i32", t2, P("ns"))                      # no sink key in the wave
+            p.s_cselect(t2, 1, 0)
+            p.s_add_u32(t1, self.s_kww, 63)
+            p.s_cmp("ge_i32", self.s_q0p, t1)                   # q0p >= kw63 + W
+            p.s_cselect(t1, 1, 0)
+            p.s_and_b32(t1, t1, t2)
+            p.s_or_b32(t0, t0, t1)
+            p.s_cmp("lg_u32", t0, 0)
+            p.s_cselect(self.s_full, 2, self.s_full)
 
     def emit_next_prefetch(self, p: Prog, deadline=None):
         """operands of the next trip's S chains: Q row fragments and the -LSE/scale rows as initial accumulators.
@@ -429,14 +455,14 @@ class DkdvGen:
                     for i in range(16):
                         p.v_accvgpr_write(acc[db][kbi][i], 0)
 
-        # ---- first three slices into stages 0, 1, 2
-        for j in range(3):
+        # ---- first slices into stages 0, 1 (, 2)
+        for j in range(self.ahead):
             p.s_mov(self.s_std, STG_BASE + j * STG_BYTES)
             p.s_mov(self.s_cstd, CST_BASE + j * 256)
             self.emit_dma_headcheck(p, "pro%d" % j)
             self.emit_dma_issue(p)
             self.emit_dma_step(p)
-        p.s_waitcnt(vmcnt=2 * (2 * self.HALVES + 1), note="V image, K fragments, slice 0 landed (slices 1, 2 in flight)")
+        p.s_waitcnt(vmcnt=(self.ahead - 1) * (2 * self.HALVES + 1), note="V image, K fragments, slice 0 landed (slices 1, 2 in flight)")
         p.s_barrier()
         # operands of the first trip
         p.v_add_u32(self.a_rown_e, STG_BASE, self.l_row_e)
@@ -449,10 +475,10 @@ class DkdvGen:
         self.emit_class(p)
         p.s_mov(self.s_st, STG_BASE)
         p.s_mov(self.s_stn, STG_BASE + STG_BYTES)
-        p.s_mov(self.s_std, STG_BASE + 3 * STG_BYTES)
+        p.s_mov(self.s_std, STG_BASE + self.ahead * STG_BYTES)
         p.s_mov(self.s_cst, CST_BASE)
         p.s_mov(self.s_cstn, CST_BASE + 256)
-        p.s_mov(self.s_cstd, CST_BASE + 768)
+        p.s_mov(self.s_cstd, CST_BASE + 256 * self.ahead)
         if self.stamps:
             for r in self.v_sum:
                 p.v_mov(r, 0)
@@ -478,7 +504,7 @@ class DkdvGen:
         p.s_cbranch("scc0", "L_cmphead%=")
         p.label("L_top_b%=")
         p.s_cmp("lg_u32", self.s_full, 0)
-        p.s_waitcnt(vmcnt=2 * self.HALVES + 1, note="slice t+1 landed (own pieces); slice t+2 may be in flight")
+        p.s_waitcnt(vmcnt=(self.ahead - 2) * (2 * self.HALVES + 1), note="slice t+1 landed (own pieces); slice t+2 may be in flight")
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="S-chain operands of this slice (fetched at the end of the last trip)")
         if self.stamps:      # head time: loop head + waits + barrier
@@ -489,6 +515,9 @@ class DkdvGen:
             p.v_add_u32(self.v_sum[2], 1, self.v_sum[2])
             p.s_cmp("lg_u32", self.s_tmp[3], 0)
         p.s_cbranch("scc0", "L_edge%=")
+        if self.dead:
+            p.s_cmp("eq_u32", self.s_tmp[3] if self.stamps else self.s_full, 2)
+            p.s_cbranch("scc1", "L_dead%=")
         return p
 
     def out_of_line(self) -> Prog:
@@ -584,24 +613,7 @@ class DkdvGen:
         # operands of the next trip (stage t + 1, landed before this trip's barrier)
         n_mfma = 4 * self.DK + 8 * self.DB
         self.emit_next_prefetch(p, deadline=max(200, n_mfma * 32 - 900))
-        # scalar state of the next trip (its class assumes the same q head; a head change redoes it out of line)
-        p.s_add_u32(self.s_q0p, self.s_q0p, 32)
-        p.s_add_u32(self.s_t, self.s_t, 1)
-        p.s_add_u32(self.s_cq, self.s_cq, 1)
-        self.emit_class(p)
-        t0 = self.s_tmp[3]
-        p.s_mov(self.s_st, self.s_stn)
-        p.s_add_u32(t0, self.s_stn, STG_BYTES - STG_BASE)
-        p.s_and_b32(t0, t0, 0xFFFF)
-        p.s_add_u32(self.s_stn, t0, STG_BASE)
-        p.s_add_u32(t0, self.s_std, STG_BYTES - STG_BASE)
-        p.s_and_b32(t0, t0, 0xFFFF)
-        p.s_add_u32(self.s_std, t0, STG_BASE)
-        p.s_mov(self.s_cst, self.s_cstn)
-        p.s_add_u32(t0, self.s_cstn, 256)
-        p.s_and_b32(self.s_cstn, t0, 1023)
-        p.s_add_u32(t0, self.s_cstd, 256)
-        p.s_and_b32(self.s_cstd, t0, 1023)
+        self.emit_trip_state(p)
         self.apply_ablate(p)
         return p
 
@@ -624,6 +636,40 @@ class DkdvGen:
             if "mfma_acc" in self.ablate and k == "mfma" and it.tag in ("dV", "dK"): drop.append(it)
         ids = set(id(x) for x in drop)
         p.items = [it for it in p.items if id(it) not in ids]
+
+    def emit_trip_state(self, p: Prog):
+        """scalar state of the next trip (its class assumes the same q head; a head change redoes it out of line)"""
+        p.s_add_u32(self.s_q0p, self.s_q0p, 32)
+        p.s_add_u32(self.s_t, self.s_t, 1)
+        p.s_add_u32(self.s_cq, self.s_cq, 1)
+        self.emit_class(p)
+        t0 = self.s_tmp[3]
+        p.s_mov(self.s_st, self.s_stn)
+        p.s_add_u32(t0, self.s_stn, STG_BYTES - STG_BASE)
+        p.s_and_b32(t0, t0, 0xFFFF)
+        p.s_add_u32(self.s_stn, t0, STG_BASE)
+        p.s_add_u32(t0, self.s_std, STG_BYTES - STG_BASE)
+        p.s_and_b32(t0, t0, 0xFFFF)
+        p.s_add_u32(self.s_std, t0, STG_BASE)
+        p.s_mov(self.s_cst, self.s_cstn)
+        p.s_add_u32(t0, self.s_cstn, 256)
+        p.s_and_b32(self.s_cstn, t0, 1023)
+        p.s_add_u32(t0, self.s_cstd, 256)
+        p.s_and_b32(self.s_cstd, t0, 1023)
+
+    def dead_body(self) -> Prog:
+        """a trip in which no row of the slice sees any key of this wave: the wave keeps the slice stream and its scalar state
+        going (its LDS-DMA pieces, the next trip's S-chain operands) and computes nothing"""
+        p = Prog()
+        self.pool_next = 0
+        p.v_add_u32(self.a_rown_e, self.s_stn, self.l_row_e)
+        p.v_xor(self.a_rown_o, 32, self.a_rown_e)
+        p.v_add_u32(self.a_cn, self.s_cstn, self.l_c)
+        self.emit_dma_issue(p, spread=False)
+        self.emit_dma_step(p)
+        self.emit_next_prefetch(p)
+        self.emit_trip_state(p)
+        return p
 
     # ------------------------------------------------------------------ epilogue
     def epilogue(self) -> Prog:
@@ -736,6 +782,10 @@ class DkdvGen:
                 body = insert_waits(body, strict_tail=False)
             body = fix_hazards(body, loop=True)
             items += body
+            items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        if self.dead:
+            items.append(Instr("label", mods={"label": "L_dead%="}, kind="label", cost=0))
+            items += fix_hazards(insert_waits(self.dead_body().items, strict_tail=False), loop=True)
             items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
         items += finish_block(self.out_of_line().items)
         items += finish_block(self.epilogue().items)
