@@ -767,15 +767,19 @@ class DkdvGen:
         p.s_waitcnt(vmcnt=0)
         return p
 
+    def trip_bodies(self):
+        """(label or None for the fall-through body behind the loop head, program) of the trip bodies"""
+        return [(None, self.trip_body(False)), ("L_edge%=", self.trip_body(True))]
+
     # ------------------------------------------------------------------ whole program
     def build(self):
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)
-        for edge in (False, True):
-            body = self.trip_body(edge).items
-            if edge:
-                items.append(Instr("label", mods={"label": "L_edge%="}, kind="label", cost=0))
+        for lbl, prog in self.trip_bodies():
+            body = prog.items
+            if lbl:
+                items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:
                 body = schedule(body)
             if "waits" not in self.ablate:      # (knock-out build: no LDS waits at all, timing only)

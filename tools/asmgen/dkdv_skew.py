@@ -43,8 +43,9 @@ PARAMS = [
 
 
 class DkdvSkewGen(DkdvGen):
-    def __init__(self, dtype="bf16", D=80, sched=True, npool=12, dma_t0=40, dma_dt=None, ablate=()):
+    def __init__(self, dtype="bf16", D=80, sched=True, npool=12, dma_t0=40, dma_dt=None, ablate=(), halves=True):
         assert D in (64, 80, 96)
+        self.halves = halves            # trip bodies for slices that touch only one of the wave's two 32-key blocks
         if dma_dt is None:          # ten pieces per trip above head dim 64: spread over the whole trip (C4: -4 % against 100)
             dma_dt = 140 if D > 64 else 100
         super().__init__(dtype, sched=sched, sfirst=48, npool=npool, dma_t0=dma_t0, dma_dt=dma_dt, D=D, ablate=ablate, dead=False)
@@ -146,15 +147,43 @@ class DkdvSkewGen(DkdvGen):
         p.s_mov(self.d_c[2], 0)
 
     def emit_class(self, p: Prog, q0p=None):
-        """s_full = 1 <=> every key of the wave is causal for and inside the window of every one of the 32 rows at q0p"""
+        """s_full = class of (the wave's 64 keys) x (the 32 rows at q0p): 1 <=> every key is causal for and inside the window
+        of every row; 3 / 4 <=> no row sees any key of the SECOND / FIRST 32-key block (the other one is masked element by
+        element): a wave's first slice touches only its first key block, its last slice only the second - two of its T
+        trips per head; else 0 (both blocks masked element by element)"""
         q0p = self.s_q0p if q0p is None else q0p
-        t0, t1 = self.s_tmp[1], self.s_tmp[2]
+        t0, t1, t2 = self.s_tmp[1], self.s_tmp[2], self.s_tmp[0]
         p.s_cmp("le_i32", self.s_kw63, q0p)
         p.s_cselect(t0, 1, 0)
         p.s_add_u32(t1, q0p, 31)
         p.s_cmp("gt_i32", self.s_kww, t1)
         p.s_cselect(t1, 1, 0)
         p.s_and_b32(self.s_full, t0, t1)
+        if self.halves:
+            # second block (keys kw63 - 31 .. kw63) dead: behind every row (kw63 - 31 > q0p + 31) or out of every window
+            # (q0p - kw63 >= W: q0p >= kww + 63); first block (kw63 - 63 .. kw63 - 32): kw63 - 63 > q0p + 31, q0p >= kww + 31
+            p.s_add_u32(t1, q0p, 62)
+            p.s_cmp("gt_i32", self.s_kw63, t1)
+            p.s_cselect(t0, 1, 0)
+            p.s_add_u32(t1, self.s_kww, 63)
+            p.s_cmp("ge_i32", q0p, t1)
+            p.s_cselect(t1, 1, 0)
+            p.s_or_b32(t0, t0, t1)                             # second block dead
+            p.s_add_u32(t1, q0p, 94)
+            p.s_cmp("gt_i32", self.s_kw63, t1)
+            p.s_cselect(t2, 1, 0)
+            p.s_add_u32(t1, self.s_kww, 31)
+            p.s_cmp("ge_i32", q0p, t1)
+            p.s_cselect(t1, 1, 0)
+            p.s_or_b32(t2, t2, t1)                             # first block dead
+            p.s_cmp("lg_u32", t0, t2)                          # exactly one of them (both: the masks make zeros of it)
+            p.s_cselect(t1, 1, 0)
+            p.s_and_b32(t0, t0, t1)
+            p.s_and_b32(t2, t2, t1)
+            p.s_cmp("lg_u32", t0, 0)
+            p.s_cselect(self.s_full, 3, self.s_full)
+            p.s_cmp("lg_u32", t2, 0)
+            p.s_cselect(self.s_full, 4, self.s_full)
 
     # ------------------------------------------------------------------ prologue
     def prologue(self) -> Prog:
@@ -335,7 +364,18 @@ class DkdvSkewGen(DkdvGen):
         p.s_barrier()
         p.s_waitcnt(lgkmcnt=0, note="S-chain operands of this trip (fetched at the end of the last one)")
         p.s_cbranch("scc0", "L_edge%=")
+        if self.halves:
+            p.s_cmp("eq_u32", self.s_full, 3)
+            p.s_cbranch("scc1", "L_e0%=")
+            p.s_cmp("eq_u32", self.s_full, 4)
+            p.s_cbranch("scc1", "L_e1%=")
         return p
+
+    def trip_bodies(self):
+        b = [(None, self.trip_body(False)), ("L_edge%=", self.trip_body(True))]
+        if self.halves:
+            b += [("L_e0%=", self.trip_body(True, live=(0,))), ("L_e1%=", self.trip_body(True, live=(1,)))]
+        return b
 
     def out_of_line(self) -> Prog:
         p = Prog()
@@ -345,7 +385,8 @@ class DkdvSkewGen(DkdvGen):
         return p
 
     # ------------------------------------------------------------------ one trip
-    def trip_body(self, edge: bool) -> Prog:
+    def trip_body(self, edge: bool, live=(0, 1)) -> Prog:
+        """live: the wave's 32-key blocks that take part (the other one is seen by no row of the slice)"""
         p = Prog()
         dt = self.dtype
         self.pool_next = 0
@@ -357,20 +398,20 @@ class DkdvSkewGen(DkdvGen):
         p.v_add_u32(self.a_rown_e, self.s_stnw, self.l_row_e)
         p.v_xor(self.a_rown_o, 32, self.a_rown_e)
         p.v_add_u32(self.a_cn, self.s_cstnw, self.l_c)
-        for kbi in range(2):
+        for kbi in live:
             for g4 in range(4):
                 p.ds_read_b128(self.DPACC[kbi][4 * g4:4 * g4 + 4], self.a_c, 128 + 32 * g4, mem=("stage_r",))
         # fetch stage t + 3
         self.emit_dma_issue(p, spread=True)
         self.emit_dma_step(p)
         # ---- [A] S' = Q K^T - LSE/scale
-        for kbi in range(2):
+        for kbi in live:
             for ks in range(self.DK):
                 p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
         if edge:
             p.v_sub_u32(self.v_d[0], self.s_q0p, self.v_kh, note="(q0 + 4 h) - key")
             p.v_sub_u32(self.v_d[1], self.v_d[0], 32)
-        for kbi in range(2):
+        for kbi in live:
             for v in range(16):
                 x = self.SACC[kbi][v]
                 p.v_mul_f32(x, P("c_log2"), x)
@@ -388,9 +429,9 @@ class DkdvSkewGen(DkdvGen):
             base = self.a_row_o if ks & 1 else self.a_row_e
             fa = self.pool()
             p.ds_read_b128(fa, base, 8192 + 512 * (ks >> 1), mem=("stage_r",), note="dO rows, k-step %d" % ks)
-            for kbi in range(2):
+            for kbi in live:
                 p.mfma(dt, self.DPACC[kbi], fa, self.VF[kbi][ks], self.DPACC[kbi], tag="dP")
-        for kbi in range(2):
+        for kbi in live:
             for v in range(16):
                 p.v_mul_f32(self.DPACC[kbi][v], self.SACC[kbi][v], self.DPACC[kbi][v])
             for s in range(2):
@@ -404,12 +445,12 @@ class DkdvSkewGen(DkdvGen):
                     f = self.pool()
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, img + 2048 * (2 * s) + 512 * db, mem=("stage_r",))
                     p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, img + 2048 * (2 * s + 1) + 512 * db, mem=("stage_r",))
-                    for kbi in range(2):
+                    for kbi in live:
                         if which == "dV":
                             p.mfma(dt, self.DV[db][kbi], f, self.PPK[kbi][s], self.DV[db][kbi], tag="dV")
                         else:
                             p.mfma(dt, self.DKA[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DKA[db][kbi], tag="dK")
-        n_mfma = 4 * self.DK + 8 * self.DB
+        n_mfma = (4 * self.DK + 8 * self.DB) * len(live) // 2
         self.emit_next_prefetch(p, deadline=max(200, n_mfma * 32 - 900))
         # ---- scalar state of the next trip: r' = r + 1 (mod T), the trip after it r'' (its stage follows s_stn in the ring)
         t0 = self.s_tmp[0]          # (free again behind the DMA issue, which the register dependences order in front)

@@ -56,13 +56,14 @@ PARAMS = [
 class DqGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
         self.persist = persist
         if sfirst is None:
             sfirst = (44 if stamps else 48) if persist else 56
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
+        self.dead = dead                  # tile class 3 and its body
         self.dma_t0, self.dma_dt = dma_t0, dma_dt   # deadlines of the eight LDS-DMA pieces inside a trip (cycles of the model)
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
         # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
@@ -206,6 +207,22 @@ class DqGen(WorkList):
         p.s_cselect(t[1], 2, 1)
         p.s_cmp("lg_u32", t[0], 0)
         p.s_cselect(self.s_cls, 0, t[1])
+        if self.dead:
+            # 3: no row of the wave sees any key of the tile - every key lies behind every row (k0 > pwhi), or the tile holds
+            # no sink key and every key has left every row's window (k0 + 63 <= pw0 - W): waves that own different ROWS
+            # (MHA, groups of 2) walk tiles that only the other waves' rows can see (fwd.py, class 4)
+            p.s_cmp("gt_i32", self.s_k0, self.s_pwhi)
+            p.s_cselect(t[0], 1, 0)
+            p.s_sub_i32(t[1], self.s_pw0, P("W"))
+            p.s_add_u32(t[2], self.s_k0, 63)
+            p.s_cmp("le_i32", t[2], t[1])
+            p.s_cselect(t[1], 1, 0)
+            p.s_cmp("ge_i32", self.s_k0, P("ns"))
+            p.s_cselect(t[2], 1, 0)
+            p.s_and_b32(t[1], t[1], t[2])
+            p.s_or_b32(t[0], t[0], t[1])
+            p.s_cmp("lg_u32", t[0], 0)
+            p.s_cselect(self.s_cls, 3, self.s_cls)
 
     # ------------------------------------------------------------------ prologue
     def prologue(self) -> Prog:
@@ -363,16 +380,31 @@ class DqGen(WorkList):
         p.s_cbranch("scc1", "L_full%=")
         p.s_cmp("eq_u32", self.s_cls, 1)
         p.s_cbranch("scc1", "L_edge%=")
+        if self.dead:
+            p.s_cmp("eq_u32", self.s_cls, 3)
+            p.s_cbranch("scc1", "L_dead%=")
         p.s_branch("L_sink%=")
         return p
 
     # ------------------------------------------------------------------ one tile
     def tile_body(self, cls: int) -> Prog:
-        """cls: 0 full, 1 edge, 2 edge with sink keys"""
+        """cls: 0 full, 1 edge, 2 edge with sink keys, 3 dead (the wave keeps the K / V stream and its state going, computes
+        nothing)"""
         p = Prog()
         dt = self.dtype
         self.pool_next = 0
         st = self.s_tmp
+        if cls == 3:
+            p.v_add_u32(self.a_kn_e, self.s_stn, self.l_row_e)
+            p.v_xor(self.a_kn_o, 32, self.a_kn_e)
+            if self.persist:
+                self.emit_dma_stream_tile(p, spread=False)
+            else:
+                p.s_add_u32(st[4], self.s_it, 3)
+                self.emit_dma_tile(p, st[4], spread=False)
+            self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)
+            self.emit_tile_advance(p)
+            return p
         p.v_add_u32(self.a_k_e, self.s_st, self.l_row_e)
         p.v_xor(self.a_k_o, 32, self.a_k_e)
         p.v_add_u32(self.a_v_e, 16384, self.a_k_e)
@@ -452,7 +484,12 @@ class DqGen(WorkList):
                         p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], self.DQ[rb][db], tag="dQ")
         # first K fragments of the next tile (landed before this trip's barrier)
         self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=(8 * self.DK + 8 * self.DB) * 32 - 300)
-        # next trip
+        self.emit_tile_advance(p)
+        return p
+
+    def emit_tile_advance(self, p: Prog):
+        """next trip: ring offsets, first key and class of its tile (the masks of the current tile read k0 first)"""
+        st = self.s_tmp
         p.s_add_u32(self.s_it, self.s_it, 1)
         t0 = st[3]
         p.s_mov(self.s_st, self.s_stn)
@@ -460,8 +497,7 @@ class DqGen(WorkList):
         p.s_and_b32(self.s_stn, t0, LDS_BYTES - 1)
         p.s_add_u32(t0, self.s_std, STG_BYTES)
         p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
-        self.emit_tile_state(p, self.s_it)      # of the next trip (the masks above read the current k0 first)
-        return p
+        self.emit_tile_state(p, self.s_it)
 
     # ------------------------------------------------------------------ epilogue
     def epilogue(self) -> Prog:
@@ -720,7 +756,7 @@ class DqGen(WorkList):
         items = []
         items += finish_block(self.prologue_pk().items)
         items += insert_waits(self.loop_top().items)
-        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")):
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()):
             body = self.tile_body(cls).items
             items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:
@@ -781,7 +817,7 @@ class DqGen(WorkList):
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)
-        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")):
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()):
             body = self.tile_body(cls).items
             items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:

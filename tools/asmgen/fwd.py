@@ -51,7 +51,7 @@ PARAMS = [
 class FwdGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", kpre=True, kpre_dl=300, persist=True, trans_sched=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", kpre=True, kpre_dl=300, persist=True, trans_sched=True, dead=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         self.persist = persist
@@ -67,6 +67,7 @@ class FwdGen(WorkList):
         # LDS-DMA deadlines inside a trip (early and staggered; placing them in the PV half measured 0.8 % slower)
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
+        self.dead = dead                  # tile class 4 (emit_class) and the iteration bodies that skip dead tiles
         # the first four K row fragments of the NEXT iteration's S^T chains are read at the end of the current one (their
         # latency passes under the loop head instead of in front of the first MFMA); needs tile i+2 landed at barrier i
         self.kpre, self.kpre_dl = kpre, kpre_dl
@@ -166,7 +167,7 @@ class FwdGen(WorkList):
                     k += 1
 
     def emit_class(self, p: Prog, k0):
-        """s_cls of the tile starting at key k0: 0 full, 1 edge (no sink key in the tile), 2 edge with sink keys"""
+        """s_cls of the tile starting at key k0: 0 full, 1 edge (no sink key in the tile), 2 edge with sink keys, 4 dead"""
         t = self.s_tmp
         p.s_add_u32(t[0], k0, 63)
         p.s_cmp("le_i32", t[0], self.s_pw0)
@@ -183,6 +184,22 @@ class FwdGen(WorkList):
         p.s_cselect(t[1], 2, 1)
         p.s_cmp("lg_u32", t[0], 0)
         p.s_cselect(self.s_cls, 0, t[1])
+        if self.dead:
+            # 4: no row of the wave sees any key of the tile - every key lies behind every row (k0 > pwhi), or the tile holds
+            # no sink key and every key has left every row's window (k0 + 63 <= pw0 - W).  Workgroups whose waves own
+            # different ROWS (MHA, groups of 2: 4 / hpw row groups) walk tiles that only the other waves' rows can see.
+            p.s_cmp("gt_i32", k0, self.s_pwhi)
+            p.s_cselect(t[0], 1, 0)
+            p.s_sub_i32(t[1], self.s_pw0, P("W"))
+            p.s_add_u32(t[2], k0, 63)
+            p.s_cmp("le_i32", t[2], t[1])
+            p.s_cselect(t[1], 1, 0)
+            p.s_cmp("ge_i32", k0, P("ns"))
+            p.s_cselect(t[2], 1, 0)
+            p.s_and_b32(t[1], t[1], t[2])
+            p.s_or_b32(t[0], t[0], t[1])
+            p.s_cmp("lg_u32", t[0], 0)
+            p.s_cselect(self.s_cls, 4, self.s_cls)
 
     # ------------------------------------------------------------------ phases
     def emit_k_prefetch(self, p: Prog, e, o, deadline=None):
@@ -331,10 +348,11 @@ class FwdGen(WorkList):
                         if not self.sub_is(kh, rb, "dead"):
                             p.mfma(dt, self.OACC[rb][db], f, pf[rb], self.OACC[rb][db], tag="PV")
 
-    def emit_next_class(self, p: Prog, it_next):
+    def emit_next_class(self, p: Prog, it_next, cur_dead=False):
         """state of the trip that processes tile it_next in E / C: first key and class of the tile after it (the one
-        that trip computes S^T and the maximum of), folded with the trip's parity into the dispatch code 4 par + class
-        (class 3: there is no next tile)"""
+        that trip computes S^T and the maximum of), folded with the trip's parity and with whether tile it_next itself is
+        dead (cur_dead: known where this is emitted) into the dispatch code (2 cur_dead + par) 8 + class (class 3: there is
+        no next tile, 4: the next tile is dead)"""
         t = self.s_tmp
         p.s_add_u32(t[3], it_next, 1)
         self.emit_tile_of(p, t[4], t[3])
@@ -343,8 +361,10 @@ class FwdGen(WorkList):
         p.s_cmp("lt_u32", t[3], self.r_nt)
         p.s_cselect(self.s_cls, self.s_cls, 3)
         p.s_and_b32(t[0], it_next, 1)
-        p.s_lshl_b32(t[0], t[0], 2)
+        p.s_lshl_b32(t[0], t[0], 3)
         p.s_add_u32(self.s_cls, self.s_cls, t[0])
+        if cur_dead:
+            p.s_add_u32(self.s_cls, self.s_cls, 16)
 
     # ------------------------------------------------------------------ prologue
     def prologue(self) -> Prog:
@@ -510,11 +530,19 @@ class FwdGen(WorkList):
         else:
             p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
             p.s_barrier()
-        for code in (0, 4, 1, 5, 3, 7, 2):
+        codes = self.body_codes()
+        for code in codes[:-1]:
             p.s_cmp("eq_u32", self.s_cls, code)
             p.s_cbranch("scc1", "L_body%d%%=" % code)
-        p.s_branch("L_body6%=")
+        p.s_branch("L_body%d%%=" % codes[-1])
         return p
+
+    def body_codes(self):
+        """dispatch codes (2 cur_dead + par) 8 + class of the iteration bodies, the frequent ones first"""
+        live = [8 * par + c for c in (0, 1, 3, 2) for par in (0, 1)]
+        if not self.dead:
+            return live
+        return live + [8 * par + 4 for par in (0, 1)] + [16 + 8 * par + c for c in (4, 0, 1, 3, 2) for par in (0, 1)]
 
     def rescale(self) -> Prog:
         """out of line: O and l of the rows whose reference point moved are multiplied by alpha (1 elsewhere)"""
@@ -538,8 +566,9 @@ class FwdGen(WorkList):
         return p
 
     # ------------------------------------------------------------------ one iteration
-    def body(self, par: int, cls_next: int) -> Prog:
-        """par: SS[par] holds tile i (its exp / PV run here), SS[par ^ 1] receives tile i+1; cls_next 0..2, 3 = none"""
+    def body(self, par: int, cls_next: int, cur_dead: bool = False) -> Prog:
+        """par: SS[par] holds tile i (its exp / PV run here), SS[par ^ 1] receives tile i+1; cls_next 0..2, 3 = none, 4 = tile
+        i+1 is dead for this wave (no S^T, no softmax bookkeeping); cur_dead: tile i is (nothing to exponentiate or add)"""
         p = Prog()
         self.pool_next = 0
         st = self.s_tmp
@@ -553,11 +582,12 @@ class FwdGen(WorkList):
         else:
             p.s_add_u32(st[4], self.s_it, 3)
             self.emit_dma_tile(p, st[4], spread=True)
-        if cls_next != 3:
+        if cls_next not in (3, 4):
             self.emit_A(p, par ^ 1, self.a_k_e, self.a_k_o, pre=self.kpre)
-        self.emit_E(p, par)
-        self.emit_C(p, par)
-        if cls_next != 3:
+        if not cur_dead:
+            self.emit_E(p, par)
+            self.emit_C(p, par)
+        if cls_next not in (3, 4):
             self.emit_M(p, par ^ 1, cls_next, self.s_k0n)
         else:
             p.s_mov_b64(self.s_flag, 0)
@@ -568,7 +598,7 @@ class FwdGen(WorkList):
         p.s_and_b32(self.s_stn, t0, LDS_BYTES - 1)
         p.s_add_u32(t0, self.s_std, STG_BYTES)
         p.s_and_b32(self.s_std, t0, LDS_BYTES - 1)
-        self.emit_next_class(p, self.s_it)
+        self.emit_next_class(p, self.s_it, cur_dead=(cls_next == 4))
         if self.kpre:            # K image of tile i+2 (landed before this iteration's barrier): addresses + first fragments
             p.v_add_u32(self.a_k_e, self.s_stn, self.l_row_e)
             p.v_xor(self.a_k_o, 32, self.a_k_e)
@@ -915,10 +945,10 @@ class FwdGen(WorkList):
         items = []
         items += finish_block(self.prologue_pk().items)
         items += insert_waits(self.loop_top().items)
-        for par in range(2):
-            for cls in range(4):
-                b = self.body(par, cls).items
-                items.append(Instr("label", mods={"label": "L_body%d%%=" % (4 * par + cls)}, kind="label", cost=0))
+        for code in self.body_codes():
+            if True:
+                b = self.body((code >> 3) & 1, code & 7, cur_dead=bool(code & 16)).items
+                items.append(Instr("label", mods={"label": "L_body%d%%=" % code}, kind="label", cost=0))
                 if self.do_sched:
                     b = schedule(b)
                 b = insert_waits(b)
@@ -955,10 +985,10 @@ class FwdGen(WorkList):
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)
-        for par in range(2):
-            for cls in range(4):
-                b = self.body(par, cls).items
-                items.append(Instr("label", mods={"label": "L_body%d%%=" % (4 * par + cls)}, kind="label", cost=0))
+        for code in self.body_codes():
+            if True:
+                b = self.body((code >> 3) & 1, code & 7, cur_dead=bool(code & 16)).items
+                items.append(Instr("label", mods={"label": "L_body%d%%=" % code}, kind="label", cost=0))
                 if self.do_sched:
                     b = schedule(b)
                 b = insert_waits(b)
