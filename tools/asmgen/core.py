@@ -187,6 +187,10 @@ class Instr:
             if k == "dma":
                 t += " lds"
             return t
+        if self.op == "v_pk_mul_f32":
+            b = self.src[1]
+            bt = "%s[%d:%d]" % (b.kind, b.idx, b.idx + 1) if m.get("pk_bcast") else b.text()
+            return "v_pk_mul_f32 %s, %s, %s%s" % (self.dst[0].text(), self.src[0].text(), bt, " op_sel_hi:[1,0]" if m.get("pk_bcast") else "")
         ops = [d.text() for d in self.dst if d.kind not in ("scc",) and not (d.kind == "vcc" and m.get("implicit_vcc"))]
         ops += [s.text() for s in self.src if not (isinstance(s, Reg) and s.kind == "scc")]
         t = self.op + (" " + ", ".join(ops) if ops else "")
@@ -299,6 +303,14 @@ class Prog:
     def v_fma_f32(self, d, a, b, c, note=""): return self._valu("v_fma_f32", d, [a, b, c], note)
     def v_mul_f32(self, d, a, b, note=""): return self._valu("v_mul_f32", d, [a, b], note)
     def v_add_f32(self, d, a, b, note=""): return self._valu("v_add_f32", d, [a, b], note)
+
+    def v_pk_mul_f32(self, d, a, b, bcast_b=False, note=""):
+        """two f32 products per lane in one issue slot: d[0:1] = a[0:1] * b[0:1]; bcast_b: b is ONE register whose value
+        multiplies both halves (op_sel_hi:[1,0]; the register pair named in the text starts at b, its second register is
+        not read).  Register pairs are even-aligned (gfx90a+)."""
+        assert d.n == 2 and a.n == 2 and d.idx % 2 == 0 and a.idx % 2 == 0
+        assert (b.n == 1 and b.idx % 2 == 0) if bcast_b else (b.n == 2 and b.idx % 2 == 0)
+        return self.add(Instr("v_pk_mul_f32", [d], [a, b], mods={"pk_bcast": bool(bcast_b)}, kind="valu", cost=4, note=note))
     def v_sub_f32(self, d, a, b, note=""): return self._valu("v_sub_f32", d, [a, b], note)
     def v_max_f32(self, d, a, b, note=""): return self._valu("v_max_f32", d, [a, b], note)
     def v_max3_f32(self, d, a, b, c, note=""): return self._valu("v_max3_f32", d, [a, b, c], note)

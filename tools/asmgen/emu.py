@@ -446,6 +446,18 @@ class Workgroup:
             self.wr_v(w, d0, nx); self.wr_v(w, d1, ny); return
         if op == "v_readfirstlane_b32":
             self.wr_s(w, ins.dst[0], int(self.rd_v(w, ins.src[0])[0])); return
+        if op == "v_pk_mul_f32":
+            d, a, b = ins.dst[0], ins.src[0], ins.src[1]
+            bc = ins.mods.get("pk_bcast")
+            res = []
+            for h in range(2):
+                x = _f32(self.rd_v(w, Reg(a.kind, a.idx + h, 1)))
+                y = _f32(self.rd_v(w, Reg(b.kind, b.idx + (0 if bc else h), 1)))
+                with np.errstate(all="ignore"):
+                    res.append(_u32(x * y))
+            for h in range(2):
+                self.wr_v(w, Reg(d.kind, d.idx + h, 1), res[h])
+            return
         s = [self.rd_v(w, o) for o in ins.src]
         d = ins.dst[0]
         u64 = lambda x: x.astype(np.uint64)
