@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import struct
 import threading
 
 import torch
@@ -132,16 +133,13 @@ def last_path() -> str:
     return lib().sfa_last_path().decode()
 
 
+_DESC = struct.Struct("P4q4qii")        # SfaTensor's layout: one pack instead of ten ctypes field stores (1 us against 5 per
+assert _DESC.size == ctypes.sizeof(SfaTensor)   # descriptor; a backward call builds ten of them)
+
+
 def desc(t: torch.Tensor) -> SfaTensor:
     """Describe a 4-D [B,H,N,D] tensor (any B/H/N strides, unit D stride)."""
-    d = SfaTensor()
-    d.ptr = t.data_ptr()
-    for i in range(4):
-        d.shape[i] = t.shape[i]
-        d.stride[i] = t.stride(i)
-    d.dtype = SFA_DTYPE[t.dtype]
-    d.reserved = 0
-    return d
+    return SfaTensor.from_buffer_copy(_DESC.pack(t.data_ptr(), *t.shape, *t.stride(), SFA_DTYPE[t.dtype], 0))
 
 
 def check(status: int, what: str):
