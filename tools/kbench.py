@@ -42,6 +42,8 @@ CFG = {  # name: B, Hq, Hkv, N, D, ns, W, s_aux
     "slmB1": (1, 32, 8, 16384, 128, 4, 1024, False),
     "slmB1d64": (1, 32, 8, 16384, 64, 4, 256, False),
     "D32": (4, 32, 8, 8192, 32, 4, 4096, False),
+    "defaults": (4, 32, 8, 8192, 128, 4, 512, False),          # the reference's default arguments (num_sink=4, window_size=512)
+    "defaults_mha": (4, 32, 32, 8192, 128, 4, 512, False),
 }
 
 
