@@ -162,8 +162,8 @@ class Instr:
             return "s_setprio %d" % m["n"]
         if self.op == "s_memtime":
             return "s_memtime %s" % self.dst[0].text()
-        if self.op == "v_permlane32_swap_b32":
-            return "v_permlane32_swap_b32 %s, %s" % (self.dst[0].text(), self.dst[1].text())
+        if self.op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32"):
+            return "%s %s, %s" % (self.op, self.dst[0].text(), self.dst[1].text())
         if k in ("ds_read", "ds_write"):
             ops = [d.text() for d in self.dst] + [s.text() for s in self.src]
             t = "%s %s" % (self.op, ", ".join(ops))
@@ -346,6 +346,10 @@ class Prog:
     def v_permlane32_swap(self, a, b, note=""):
         """lanes 32..63 of a swap with lanes 0..31 of b"""
         return self.add(Instr("v_permlane32_swap_b32", [a, b], [a, b], kind="valu", note=note))
+
+    def v_permlane16_swap(self, a, b, note=""):
+        """16-lane rows 1 and 3 of a swap with rows 0 and 2 of b (lanes 16..31 <-> 0..15, 48..63 <-> 32..47)"""
+        return self.add(Instr("v_permlane16_swap_b32", [a, b], [a, b], kind="valu", note=note))
 
     def v_readfirstlane(self, d, a, note=""):
         return self.add(Instr("v_readfirstlane_b32", [d], [a], kind="valu", note=note))

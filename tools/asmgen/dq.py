@@ -56,7 +56,7 @@ PARAMS = [
 class DqGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True, wide64=False):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
         self.persist = persist
@@ -64,6 +64,10 @@ class DqGen(WorkList):
             sfirst = (44 if stamps else 48) if persist else 56
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dead = dead                  # tile class 3 and its body
+        # row stores of 64 contiguous bytes (4 lanes per row, 16 rows per instruction): an experiment that did not pay - C3 dQ
+        # 1.9181 vs 1.9195 ms, W = 512 0.4831 vs 0.4858, bitwise equal (profiles/r03_ab_dq_wide64.log): the stores of an item
+        # transition are not bound by the cache lines an instruction touches
+        self.wide64 = wide64 and persist
         self.dma_t0, self.dma_dt = dma_t0, dma_dt   # deadlines of the eight LDS-DMA pieces inside a trip (cycles of the model)
         # head dim: DK k-steps of 16, DB 32-wide output blocks, NCH valid 16-byte chunks per row (LDS rows stay 256 bytes:
         # chunks beyond the head dim are fetched as zeros or, when a whole 128-byte half is padding, not at all)
@@ -106,6 +110,9 @@ class DqGen(WorkList):
         self.s_koff, self.s_voff = sa("s_koff"), sa("s_voff")
         self.s_wofs = sa("s_wofs")
         self.s_cls = sa("s_cls")
+        # offsets of the 64-byte row stores: rows l and l + 16 of the two row blocks (the mask scratch of the tile bodies is
+        # idle at a transition)
+        self.vo64, self.vo64b = self.v_d, [self.v_nsh, self.v_weff]
         self.s_tmp = [sa("s_tmp%d" % i) for i in range(5)]
         if persist:
             self.wl_alloc(sa)
@@ -726,30 +733,63 @@ class DqGen(WorkList):
         p.v_lshl_add_u32(self.vo[0], t2, 4, t1)               # + 16 h bytes
         p.s_lshl_b32(st[1], P("dq_sn"), 5)
         p.v_add_u32(self.vo[1], st[1], self.vo[0])
+        if self.wide64:
+            # 64-byte row pieces: lane = 16 g + l writes bytes 16 g .. of row (first row of the block) + l; the second store of
+            # a pair the rows 16 further
+            p.v_and(t2, 15, self.lane)
+            p.v_sub_u32(t0, self.v_pos[0], P("pos0"))
+            p.v_and(t3, 31, self.lane)
+            p.v_sub_u32(t0, t0, t3)                               # first row of row block 0
+            p.v_add_u32(t0, t0, t2)
+            p.v_mul_lo_u32(t1, t0, P("dq_sn"))
+            p.v_lshrrev(t2, 4, self.lane)
+            p.v_lshl_add_u32(self.vo64[0], t2, 4, t1)
+            p.v_add_u32(self.vo64[1], st[1], self.vo64[0])
+            p.s_lshl_b32(st[1], P("dq_sn"), 4)
+            p.v_add_u32(self.vo64b[0], st[1], self.vo64[0])
+            p.v_add_u32(self.vo64b[1], st[1], self.vo64[1])
 
     def emit_stores(self, p: Prog):
-        """dQ[row, d] = scale * dQ^T[d, row] (as the one-item epilogue)"""
+        """dQ[row, d] = scale * dQ^T[d, row] (as the one-item epilogue).  wide64: the two 16-column groups of a 32-column block
+        are exchanged once more between the 16-lane rows (v_permlane32_swap + v_permlane16_swap), so that four lanes hold 64
+        contiguous bytes of one row and a store instruction touches 16 rows instead of 32 (the stores of an item transition
+        are bound by the cache lines an instruction touches)"""
         dt = self.dtype
         npair = 0
+
+        def quad(rb, db, gp, X, Y):
+            for e in range(4):
+                p.v_accvgpr_read(X[e], self.DQ[rb][db][8 * gp + e])
+                p.v_accvgpr_read(Y[e], self.DQ[rb][db][8 * gp + 4 + e])
+            for e in range(4):
+                p.v_mul_f32(X[e], P("scale"), X[e])
+                p.v_mul_f32(Y[e], P("scale"), Y[e])
+            p.v_cvt_pk(dt, X[0], X[0], X[1])
+            p.v_cvt_pk(dt, X[1], X[2], X[3])
+            p.v_cvt_pk(dt, X[2], Y[0], Y[1])
+            p.v_cvt_pk(dt, X[3], Y[2], Y[3])
+            p.v_permlane32_swap(X[0], X[2])
+            p.v_permlane32_swap(X[1], X[3])
+
         for rb in range(2):
             for db in range(self.DB):
+                if self.wide64 and 32 * db + 32 <= self.D:
+                    X0, Y0, X1, Y1 = (self.POOL[(4 * npair + i) % 8] for i in range(4))
+                    npair += 1
+                    quad(rb, db, 0, X0, Y0)
+                    quad(rb, db, 1, X1, Y1)
+                    for e in range(4):
+                        p.v_permlane32_swap(X0[e], X1[e])
+                        p.v_permlane16_swap(X0[e], X1[e])
+                    p.buffer_store(X0[0:4], self.vo64[rb], self.d_x, 0, offset=64 * db)
+                    p.buffer_store(X1[0:4], self.vo64b[rb], self.d_x, 0, offset=64 * db)
+                    continue
                 for gp in range(2):
                     if 32 * db + 16 * gp >= self.D:
                         continue
                     X, Y = self.POOL[(2 * npair) % 8], self.POOL[(2 * npair + 1) % 8]
                     npair += 1
-                    for e in range(4):
-                        p.v_accvgpr_read(X[e], self.DQ[rb][db][8 * gp + e])
-                        p.v_accvgpr_read(Y[e], self.DQ[rb][db][8 * gp + 4 + e])
-                    for e in range(4):
-                        p.v_mul_f32(X[e], P("scale"), X[e])
-                        p.v_mul_f32(Y[e], P("scale"), Y[e])
-                    p.v_cvt_pk(dt, X[0], X[0], X[1])
-                    p.v_cvt_pk(dt, X[1], X[2], X[3])
-                    p.v_cvt_pk(dt, X[2], Y[0], Y[1])
-                    p.v_cvt_pk(dt, X[3], Y[2], Y[3])
-                    p.v_permlane32_swap(X[0], X[2])
-                    p.v_permlane32_swap(X[1], X[3])
+                    quad(rb, db, gp, X, Y)
                     p.buffer_store(X[0:4], self.vo[rb], self.d_x, 0, offset=64 * db + 32 * gp)
 
     def build_pk(self):

@@ -444,6 +444,13 @@ class Workgroup:
             nx[32:] = y[:32]
             ny[:32] = x[32:]
             self.wr_v(w, d0, nx); self.wr_v(w, d1, ny); return
+        if op == "v_permlane16_swap_b32":
+            d0, d1 = ins.dst
+            x, y = self.rd_v(w, d0).copy(), self.rd_v(w, d1).copy()
+            nx, ny = x.copy(), y.copy()
+            nx[16:32] = y[0:16]; ny[0:16] = x[16:32]
+            nx[48:64] = y[32:48]; ny[32:48] = x[48:64]
+            self.wr_v(w, d0, nx); self.wr_v(w, d1, ny); return
         if op == "v_readfirstlane_b32":
             self.wr_s(w, ins.dst[0], int(self.rd_v(w, ins.src[0])[0])); return
         if op == "v_pk_mul_f32":

@@ -355,7 +355,7 @@ def fix_hazards(items: Sequence[Instr], loop: bool = False) -> List[Instr]:
                         req = max(req, 2 - since)
                     if prev.kind == "trans" and it.kind in ("valu", "trans", "mfma") and pw & rd:
                         req = max(req, 1 - since)
-                    if it.op in ("v_permlane32_swap_b32", "v_readfirstlane_b32") and pw & rd:
+                    if it.op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32", "v_readfirstlane_b32") and pw & rd:
                         req = max(req, 2 - since)
                     if prev.op == "v_readfirstlane_b32" and it.kind in ("dma", "vload", "vstore") and pw & rd:
                         req = max(req, 5 - since)
