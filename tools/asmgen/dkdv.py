@@ -70,12 +70,13 @@ class Alloc:
 
 
 class DkdvGen:
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125, D=128, ahead=3, dead=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=56, npool=12, stamps=False, ablate=(), dma_t0=40, dma_dt=125, D=128, ahead=3, dead=True, half_edges=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype = dtype
         self.do_sched = sched
         self.partials = True            # the f32 second epilogue of split sweeps
         self.dead = dead                # a third trip body for trips in which no row sees any key of the wave: no MFMA, no VALU
+        self.half_edges = half_edges    # edge trips in which no row sees one of the wave's two 32-key blocks run on the other one
         self.ahead = ahead              # slices the LDS-DMA runs ahead of the trip (3 = what the 4-deep ring allows; 2: experiment)
         assert ahead in (2, 3)
         # head dim: DK k-steps of 16 in the d contractions, DB 32-wide output blocks of dK^T / dV^T, NCH valid 16-byte
@@ -514,7 +515,7 @@ class DkdvGen:
             p.v_add_u32(self.v_sum[0], self.s_tmp[2], self.v_sum[0])
             p.v_add_u32(self.v_sum[2], 1, self.v_sum[2])
             p.s_cmp("lg_u32", self.s_tmp[3], 0)
-        p.s_cbranch("scc0", "L_edge%=")
+        p.s_cbranch("scc0", "L_edgesel%=" if self.half_edges else "L_edge%=")
         if self.dead:
             p.s_cmp("eq_u32", self.s_tmp[3] if self.stamps else self.s_full, 2)
             p.s_cbranch("scc1", "L_dead%=")
@@ -530,10 +531,36 @@ class DkdvGen:
         p.s_add_u32(self.s_q0p, P("q_row0"), P("pos0"))
         self.emit_class(p)
         p.s_branch("L_top_b%=")
+        if self.half_edges:
+            # An edge trip (only those come here): is one of the wave's two 32-key blocks out of every row's reach?  Block kb
+            # (keys kw0 + 32 kb .. + 31) is dead when all its keys lie behind every row (kw0 + 32 kb > q0p + 31) or when it
+            # holds no sink key and every key has left every row's window (q0p - (kw0 + 32 kb + 31) >= W).  The long case:
+            # block 0's sink tail - rows far beyond the window sweep 64 keys for the few sink keys among the first 32.
+            t0, t1, t2, t3 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2], self.s_tmp[3]
+            p.label("L_edgesel%=")
+            dead = []
+            for kb, acc in ((0, t2), (1, t3)):
+                p.s_add_u32(t0, self.s_q0p, 94 - 32 * kb)           # kw63 - 63 + 32 kb > q0p + 31
+                p.s_cmp("gt_i32", self.s_kw63, t0)
+                p.s_cselect(acc, 1, 0)
+                p.s_sub_u32(t0, self.s_kw63, 63 - 32 * kb)          # first key of the block >= ns
+                p.s_cmp("ge_i32", t0, P("ns"))
+                p.s_cselect(t0, 1, 0)
+                p.s_add_u32(t1, self.s_kww, 31 + 32 * kb)           # q0p >= kw0 + 32 kb + 31 + W
+                p.s_cmp("ge_i32", self.s_q0p, t1)
+                p.s_cselect(t1, 1, 0)
+                p.s_and_b32(t0, t0, t1)
+                p.s_or_b32(acc, acc, t0)
+            p.s_cmp("lg_u32", t3, 0)
+            p.s_cbranch("scc1", "L_e0%=")                          # second block dead: the first one alone
+            p.s_cmp("lg_u32", t2, 0)
+            p.s_cbranch("scc1", "L_e1%=")
+            p.s_branch("L_edge%=")
         return p
 
     # ------------------------------------------------------------------ one trip
-    def trip_body(self, edge: bool) -> Prog:
+    def trip_body(self, edge: bool, live=(0, 1)) -> Prog:
+        """live: the wave's 32-key blocks that take part (edge trips: the other one is seen by no row of the slice)"""
         p = Prog()
         dt = self.dtype
         self.pool_next = 0
@@ -547,7 +574,7 @@ class DkdvGen:
         p.v_xor(self.a_rown_o, 32, self.a_rown_e)
         p.v_add_u32(self.a_cn, self.s_cstn, self.l_c)
         # dP accumulators start from -Delta: registers 4 g4 .. +3 <- rows 8 g4 + 4 h + {0..3}
-        for kbi in range(2):
+        for kbi in live:
             for g4 in range(4):
                 p.ds_read_b128(self.DPACC[kbi][4 * g4:4 * g4 + 4], self.a_c, 128 + 32 * g4, mem=("stage_r",))
         # fetch slice t + 3
@@ -555,7 +582,7 @@ class DkdvGen:
         self.emit_dma_step(p)
         # ---- [A] S' = Q K^T - LSE/scale, key block after key block (operands and initial accumulators were fetched
         #      at the end of the previous trip)
-        for kbi in range(2):
+        for kbi in live:
             for ks in range(self.DK):
                 p.mfma(dt, self.SACC[kbi], self.QROW[ks], self.KF[kbi][ks], self.SACC[kbi], tag="S")
         self.emit_phase_stamp(p, 3)
@@ -563,7 +590,7 @@ class DkdvGen:
             p.v_sub_u32(self.v_d[0], self.s_q0p, self.v_kh, note="(q0 + pos0 + 4 h) - key")
             p.v_sub_u32(self.v_d[1], self.v_d[0], 32)
         # ---- P = exp2(c S') (+ mask), packed
-        for kbi in range(2):
+        for kbi in live:
             for v in range(16):
                 x = self.SACC[kbi][v]
                 if "mulc" not in self.ablate:
@@ -582,7 +609,7 @@ class DkdvGen:
             base = self.a_row_o if ks & 1 else self.a_row_e
             fa = self.pool()
             p.ds_read_b128(fa, base, 8192 + 512 * (ks >> 1), mem=("stage_r",), note="dO rows, k-step %d" % ks)
-            for kbi in range(2):
+            for kbi in live:
                 vb = self.a_v_o if ks & 1 else self.a_v_e
                 fv = self.pool()
                 p.ds_read_b128(fv, vb, 8192 * kbi + 512 * (ks >> 1), mem=("v_img_r",), note="V rows")
@@ -590,7 +617,7 @@ class DkdvGen:
         self.emit_phase_stamp(p, 4)
         # ---- dS = P dP', packed IN PLACE into dP registers [kbi][4 s + j] (the S registers are free from here on: the
         #      next trip's initial accumulators go there while this trip's last MFMAs run)
-        for kbi in range(2):
+        for kbi in live:
             for v in range(16):
                 p.v_mul_f32(self.DPACC[kbi][v], self.SACC[kbi][v], self.DPACC[kbi][v])
             for s in range(2):
@@ -604,14 +631,14 @@ class DkdvGen:
                     f = self.pool()
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, img + 2048 * (2 * s) + 512 * db, mem=("stage_r",))
                     p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, img + 2048 * (2 * s + 1) + 512 * db, mem=("stage_r",))
-                    for kbi in range(2):
+                    for kbi in live:
                         if which == "dV":
                             p.mfma(dt, self.DV[db][kbi], f, self.PPK[kbi][s], self.DV[db][kbi], tag="dV")
                         else:
                             p.mfma(dt, self.DKA[db][kbi], f, self.DPACC[kbi][4 * s:4 * s + 4], self.DKA[db][kbi], tag="dK")
             self.emit_phase_stamp(p, 5 if which == "dV" else 6)
         # operands of the next trip (stage t + 1, landed before this trip's barrier)
-        n_mfma = 4 * self.DK + 8 * self.DB
+        n_mfma = (4 * self.DK + 8 * self.DB) * len(live) // 2
         self.emit_next_prefetch(p, deadline=max(200, n_mfma * 32 - 900))
         self.emit_trip_state(p)
         self.apply_ablate(p)
@@ -769,7 +796,10 @@ class DkdvGen:
 
     def trip_bodies(self):
         """(label or None for the fall-through body behind the loop head, program) of the trip bodies"""
-        return [(None, self.trip_body(False)), ("L_edge%=", self.trip_body(True))]
+        b = [(None, self.trip_body(False)), ("L_edge%=", self.trip_body(True))]
+        if self.half_edges:
+            b += [("L_e0%=", self.trip_body(True, live=(0,))), ("L_e1%=", self.trip_body(True, live=(1,)))]
+        return b
 
     # ------------------------------------------------------------------ whole program
     def build(self):

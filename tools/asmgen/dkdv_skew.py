@@ -48,7 +48,7 @@ class DkdvSkewGen(DkdvGen):
         self.halves = halves            # trip bodies for slices that touch only one of the wave's two 32-key blocks
         if dma_dt is None:          # ten pieces per trip above head dim 64: spread over the whole trip (C4: -4 % against 100)
             dma_dt = 140 if D > 64 else 100
-        super().__init__(dtype, sched=sched, sfirst=48, npool=npool, dma_t0=dma_t0, dma_dt=dma_dt, D=D, ablate=ablate, dead=False)
+        super().__init__(dtype, sched=sched, sfirst=48, npool=npool, dma_t0=dma_t0, dma_dt=dma_dt, D=D, ablate=ablate, dead=False, half_edges=False)
         self.partials = False
         va, sa = self.va, self.sa
         # V fragments of the wave's keys in the accumulator registers the narrower dK^T / dV^T tiles leave free
