@@ -56,7 +56,7 @@ PARAMS = [
 class DqGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True, wide64=False):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True, wide64=False, sinkfar=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
         self.persist = persist
@@ -64,6 +64,7 @@ class DqGen(WorkList):
             sfirst = (44 if stamps else 48) if persist else 56
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dead = dead                  # tile class 3 and its body
+        self.sinkfar = sinkfar and persist   # class 4: a sink tile whose second key half nobody sees (set at item init)
         # row stores of 64 contiguous bytes (4 lanes per row, 16 rows per instruction): an experiment that did not pay - C3 dQ
         # 1.9181 vs 1.9195 ms, W = 512 0.4831 vs 0.4858, bitwise equal (profiles/r03_ab_dq_wide64.log): the stores of an item
         # transition are not bound by the cache lines an instruction touches
@@ -390,6 +391,9 @@ class DqGen(WorkList):
         if self.dead:
             p.s_cmp("eq_u32", self.s_cls, 3)
             p.s_cbranch("scc1", "L_dead%=")
+        if self.sinkfar:
+            p.s_cmp("eq_u32", self.s_cls, 4)
+            p.s_cbranch("scc1", "L_sinkfar%=")
         p.s_branch("L_sink%=")
         return p
 
@@ -412,6 +416,9 @@ class DqGen(WorkList):
             self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)
             self.emit_tile_advance(p)
             return p
+        halves = (0,) if cls == 4 else (0, 1)      # class 4: the sink tile without its second key half
+        if cls == 4:
+            cls = 2
         p.v_add_u32(self.a_k_e, self.s_st, self.l_row_e)
         p.v_xor(self.a_k_o, 32, self.a_k_e)
         p.v_add_u32(self.a_v_e, 16384, self.a_k_e)
@@ -434,7 +441,7 @@ class DqGen(WorkList):
                 p.v_sub_u32(self.v_d[rb], self.v_pos[rb], self.tmp[1])
             if cls == 2:             # sink key <=> 32 kh + o_v < ns - k0 - 4 h
                 p.v_sub_u32(self.v_nsh, P("ns"), self.tmp[1])
-        for kh in range(2):
+        for kh in halves:
             # ---- S^T = K Q^T: the eight K row fragments of this key half feed both row blocks
             kf = []
             for ks in range(self.DK):
@@ -480,7 +487,7 @@ class DqGen(WorkList):
                         d = self.DPACC[kh][rb]
                         p.v_cvt_pk(dt, d[4 * s + j], d[8 * s + 2 * j], d[8 * s + 2 * j + 1])
         # ---- dQ^T += K^T dS^T (K^T fragments: transposed reads of the K image, rows = keys)
-        for kh in range(2):
+        for kh in halves:
             for s in range(2):
                 for db in range(self.DB):
                     f = self.pool()
@@ -490,7 +497,7 @@ class DqGen(WorkList):
                     for rb in range(2):
                         p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], self.DQ[rb][db], tag="dQ")
         # first K fragments of the next tile (landed before this trip's barrier)
-        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=(8 * self.DK + 8 * self.DB) * 32 - 300)
+        self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=max(200, (8 * self.DK + 8 * self.DB) * 16 * len(halves) - 300))
         self.emit_tile_advance(p)
         return p
 
@@ -689,6 +696,24 @@ class DqGen(WorkList):
         self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o)
         p.s_mov(self.s_it, 0)
         self.emit_tile_state(p, self.s_it)
+        if self.sinkfar:
+            # The item's FIRST tile, when it is a sink tile (class 2) whose second 32-key half holds no sink key and lies
+            # outside every row's window (rows far behind the sinks: every item but the first few): class 4, the body
+            # without that half.  Decided here, once per item - the loop's own classification never yields 4.
+            t = self.s_tmp
+            p.s_add_u32(t[0], self.s_k0, 32)
+            p.s_cmp("ge_i32", t[0], P("ns"))                        # no sink key in keys k0 + 32 .. k0 + 63
+            p.s_cselect(t[1], 1, 0)
+            p.s_sub_i32(t[2], self.s_pw0, P("W"))
+            p.s_add_u32(t[0], self.s_k0, 63)
+            p.s_cmp("le_i32", t[0], t[2])                           # k0 + 63 <= pw0 - W
+            p.s_cselect(t[2], 1, 0)
+            p.s_and_b32(t[1], t[1], t[2])
+            p.s_cmp("eq_u32", self.s_cls, 2)
+            p.s_cselect(t[2], 1, 0)
+            p.s_and_b32(t[1], t[1], t[2])
+            p.s_cmp("lg_u32", t[1], 0)
+            p.s_cselect(self.s_cls, 4, self.s_cls)
 
     def prologue_pk(self) -> Prog:
         p = self.setup_pk()
@@ -796,7 +821,7 @@ class DqGen(WorkList):
         items = []
         items += finish_block(self.prologue_pk().items)
         items += insert_waits(self.loop_top().items)
-        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()):
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()) + (((4, "L_sinkfar%="),) if self.sinkfar else ()):
             body = self.tile_body(cls).items
             items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:
@@ -857,7 +882,7 @@ class DqGen(WorkList):
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)
-        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()):
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()) + (((4, "L_sinkfar%="),) if self.sinkfar else ()):
             body = self.tile_body(cls).items
             items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:
