@@ -51,7 +51,7 @@ PARAMS = [
 class FwdGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", kpre=True, kpre_dl=300, persist=True, trans_sched=True, dead=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=10, thr=8.0, dma_t0=500, dma_dt=180, D=128, ablate=(), lsum="mfma", kpre=True, kpre_dl=300, persist=True, trans_sched=True, dead=True, sinkfar=False):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched, self.thr = dtype, sched, thr
         self.persist = persist
@@ -68,6 +68,9 @@ class FwdGen(WorkList):
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dead = dead                  # tile class 4 (emit_class) and the iteration bodies that skip dead tiles
+        # an item's sink tile without the exp2 / PV of its second key half when nobody sees it: measured no faster (C3 forward
+        # 1.458 vs 1.445 ms, window 512 0.383 vs 0.383, in-process): off; the dQ kernel's version of it pays (dq.py)
+        self.sinkfar = sinkfar and persist and dead
         # the first four K row fragments of the NEXT iteration's S^T chains are read at the end of the current one (their
         # latency passes under the loop head instead of in front of the first MFMA); needs tile i+2 landed at barrier i
         self.kpre, self.kpre_dl = kpre, kpre_dl
@@ -339,6 +342,8 @@ class FwdGen(WorkList):
                 for rb in range(2):
                     if not self.lsum_valu and not self.sub_is(kh, rb, "dead"):
                         p.mfma(dt, self.LACC[rb], self.ONES, pf[rb], self.LACC[rb], tag="l")
+                if self.sub_is(kh, 0, "dead") and self.sub_is(kh, 1, "dead"):
+                    continue                                   # nobody takes this key half's V^T fragments
                 for db in range(self.DB):
                     f = self.pool()
                     off = 16384 + 8192 * kh + 512 * db
@@ -542,7 +547,10 @@ class FwdGen(WorkList):
         live = [8 * par + c for c in (0, 1, 3, 2) for par in (0, 1)]
         if not self.dead:
             return live
-        return live + [8 * par + 4 for par in (0, 1)] + [16 + 8 * par + c for c in (4, 0, 1, 3, 2) for par in (0, 1)]
+        codes = live + [8 * par + 4 for par in (0, 1)] + [16 + 8 * par + c for c in (4, 0, 1, 3, 2) for par in (0, 1)]
+        if self.sinkfar:
+            codes += [32 + c for c in (0, 1, 4, 3, 2)]           # the item's first iteration, tile 0 = a far sink tile (parity 0)
+        return codes
 
     def rescale(self) -> Prog:
         """out of line: O and l of the rows whose reference point moved are multiplied by alpha (1 elsewhere)"""
@@ -566,7 +574,7 @@ class FwdGen(WorkList):
         return p
 
     # ------------------------------------------------------------------ one iteration
-    def body(self, par: int, cls_next: int, cur_dead: bool = False) -> Prog:
+    def body(self, par: int, cls_next: int, cur_dead: bool = False, cur_sinkfar: bool = False) -> Prog:
         """par: SS[par] holds tile i (its exp / PV run here), SS[par ^ 1] receives tile i+1; cls_next 0..2, 3 = none, 4 = tile
         i+1 is dead for this wave (no S^T, no softmax bookkeeping); cur_dead: tile i is (nothing to exponentiate or add)"""
         p = Prog()
@@ -585,8 +593,10 @@ class FwdGen(WorkList):
         if cls_next not in (3, 4):
             self.emit_A(p, par ^ 1, self.a_k_e, self.a_k_o, pre=self.kpre)
         if not cur_dead:
+            self.sub = [["mask", "mask"], ["dead", "dead"]] if cur_sinkfar else None      # (sub[kh][rb])
             self.emit_E(p, par)
             self.emit_C(p, par)
+            self.sub = None
         if cls_next not in (3, 4):
             self.emit_M(p, par ^ 1, cls_next, self.s_k0n)
         else:
@@ -837,6 +847,26 @@ class FwdGen(WorkList):
         self.emit_M(p, 0, 2, self.s_k0n)
         p.s_mov(self.s_it, 0)
         self.emit_next_class(p, self.s_it)
+        if self.sinkfar:
+            # tile 0 is a sink tile whose second 32-key half holds no sink key and lies outside every row's window (rows far
+            # behind the sinks: every item but the first few): the first iteration skips that half's exp2 / PV / row sums
+            # (dispatch code + 32; its S^T and mask above were computed in full - they are masked to -inf)
+            p.s_mov(st[3], 0)
+            self.emit_tile_of(p, st[4], st[3])
+            p.s_lshl_b32(st[4], st[4], 6)                          # k0 of tile 0
+            p.s_cmp("lt_i32", st[4], P("ns"))
+            p.s_cselect(st[0], 1, 0)
+            p.s_add_u32(st[1], st[4], 32)
+            p.s_cmp("ge_i32", st[1], P("ns"))
+            p.s_cselect(st[1], 1, 0)
+            p.s_and_b32(st[0], st[0], st[1])
+            p.s_sub_i32(st[1], self.s_pw0, P("W"))
+            p.s_add_u32(st[2], st[4], 63)
+            p.s_cmp("le_i32", st[2], st[1])
+            p.s_cselect(st[1], 1, 0)
+            p.s_and_b32(st[0], st[0], st[1])
+            p.s_lshl_b32(st[0], st[0], 5)
+            p.s_add_u32(self.s_cls, self.s_cls, st[0])
         if first:
             p.s_waitcnt(vmcnt=0, note="tiles 1, 2 landed (own pieces)")
             p.s_barrier()
@@ -947,7 +977,7 @@ class FwdGen(WorkList):
         items += insert_waits(self.loop_top().items)
         for code in self.body_codes():
             if True:
-                b = self.body((code >> 3) & 1, code & 7, cur_dead=bool(code & 16)).items
+                b = self.body((code >> 3) & 1, code & 7, cur_dead=bool(code & 16), cur_sinkfar=bool(code & 32)).items
                 items.append(Instr("label", mods={"label": "L_body%d%%=" % code}, kind="label", cost=0))
                 if self.do_sched:
                     b = schedule(b)
@@ -987,7 +1017,7 @@ class FwdGen(WorkList):
         items += insert_waits(self.loop_top().items)
         for code in self.body_codes():
             if True:
-                b = self.body((code >> 3) & 1, code & 7, cur_dead=bool(code & 16)).items
+                b = self.body((code >> 3) & 1, code & 7, cur_dead=bool(code & 16), cur_sinkfar=bool(code & 32)).items
                 items.append(Instr("label", mods={"label": "L_body%d%%=" % code}, kind="label", cost=0))
                 if self.do_sched:
                     b = schedule(b)
