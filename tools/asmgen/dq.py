@@ -56,7 +56,7 @@ PARAMS = [
 class DqGen(WorkList):
     DESC, DESC_BASE = DESC, DESC_BASE
 
-    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True, wide64=False, sinkfar=True):
+    def __init__(self, dtype="bf16", sched=True, vfirst=4, sfirst=None, npool=12, D=128, ablate=(), dma_t0=40, dma_dt=120, persist=True, stamps=False, dead=True, wide64=False, sinkfar=True, edge_subs=True):
         assert dtype in ("bf16", "f16") and D in (64, 80, 96, 128)
         self.dtype, self.do_sched = dtype, sched
         self.persist = persist
@@ -65,6 +65,7 @@ class DqGen(WorkList):
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dead = dead                  # tile class 3 and its body
         self.sinkfar = sinkfar and persist   # class 4: a sink tile whose second key half nobody sees (set at item init)
+        self.edge_subs = edge_subs        # edge tiles: a 32-key x 32-row sub-block that no row sees is left out (classes 5, 6)
         # row stores of 64 contiguous bytes (4 lanes per row, 16 rows per instruction): an experiment that did not pay - C3 dQ
         # 1.9181 vs 1.9195 ms, W = 512 0.4831 vs 0.4858, bitwise equal (profiles/r03_ab_dq_wide64.log): the stores of an item
         # transition are not bound by the cache lines an instruction touches
@@ -387,7 +388,7 @@ class DqGen(WorkList):
         p.s_cmp("eq_u32", self.s_cls, 0)
         p.s_cbranch("scc1", "L_full%=")
         p.s_cmp("eq_u32", self.s_cls, 1)
-        p.s_cbranch("scc1", "L_edge%=")
+        p.s_cbranch("scc1", "L_edgesel%=" if self.edge_subs else "L_edge%=")
         if self.dead:
             p.s_cmp("eq_u32", self.s_cls, 3)
             p.s_cbranch("scc1", "L_dead%=")
@@ -419,6 +420,11 @@ class DqGen(WorkList):
         halves = (0,) if cls == 4 else (0, 1)      # class 4: the sink tile without its second key half
         if cls == 4:
             cls = 2
+        skip = set()                               # (key half, row block) sub-blocks that no row sees: classes 5 / 6 of edge tiles
+        if cls == 5:
+            cls, skip = 1, {(1, 0)}                # the diagonal tile: rows 0..31 never see keys 32..63
+        elif cls == 6:
+            cls, skip = 1, {(0, 1)}                # the window's first tile: rows 32..63 have left keys 0..31 behind
         p.v_add_u32(self.a_k_e, self.s_st, self.l_row_e)
         p.v_xor(self.a_k_o, 32, self.a_k_e)
         p.v_add_u32(self.a_v_e, 16384, self.a_k_e)
@@ -451,6 +457,8 @@ class DqGen(WorkList):
                     p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="K rows")
                 kf.append(f)
             for rb in range(2):
+                if (kh, rb) in skip:
+                    continue
                 for ks in range(self.DK):
                     p.mfma(dt, self.SACC[kh][rb], kf[ks], self.QF[rb][ks], self.SACC[kh][rb] if ks else 0, tag="S")
             # ---- dP^T = V dO^T
@@ -461,10 +469,14 @@ class DqGen(WorkList):
                 p.ds_read_b128(f, base, 8192 * kh + 512 * (ks >> 1), mem=("stage_r",), note="V rows")
                 vf.append(f)
             for rb in range(2):
+                if (kh, rb) in skip:
+                    continue
                 for ks in range(self.DK):
                     p.mfma(dt, self.DPACC[kh][rb], vf[ks], self.DOF[rb][ks], self.DPACC[kh][rb] if ks else 0, tag="dP")
             # ---- P, dS, packed in place
             for rb in range(2):
+                if (kh, rb) in skip:
+                    continue
                 for v in range(16):
                     x, y = self.SACC[kh][rb][v], self.DPACC[kh][rb][v]
                     if "fma" not in self.ablate:
@@ -495,10 +507,32 @@ class DqGen(WorkList):
                     p.ds_read_b64_tr_b16(f[0:2], self.a_tr0, off + 2048 * (2 * s), mem=("stage_r",))
                     p.ds_read_b64_tr_b16(f[2:4], self.a_tr1, off + 2048 * (2 * s + 1), mem=("stage_r",))
                     for rb in range(2):
-                        p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], self.DQ[rb][db], tag="dQ")
+                        if (kh, rb) not in skip:
+                            p.mfma(dt, self.DQ[rb][db], f, self.DPACC[kh][rb][4 * s:4 * s + 4], self.DQ[rb][db], tag="dQ")
         # first K fragments of the next tile (landed before this trip's barrier)
         self.emit_k_prefetch(p, self.a_kn_e, self.a_kn_o, deadline=max(200, (8 * self.DK + 8 * self.DB) * 16 * len(halves) - 300))
         self.emit_tile_advance(p)
+        return p
+
+    def edge_selector(self) -> Prog:
+        """behind the loop head, edge tiles only: is a 32-key x 32-row sub-block out of reach?  (kh 1, rb 0): every key of the
+        second half lies behind rows pw0 .. pw0 + 31 (k0 >= pw0: the diagonal tile); (kh 0, rb 1): every key of the first half
+        has left the window of rows pw0 + 32 .. (k0 + 31 <= pw0 + 32 - W: the window's first tile; class 1 tiles hold no sink
+        key).  Both at once (windows below 64): the generic edge body."""
+        p = Prog()
+        t = self.s_tmp
+        p.label("L_edgesel%=")
+        p.s_cmp("ge_i32", self.s_k0, self.s_pw0)
+        p.s_cselect(t[0], 1, 0)
+        p.s_sub_i32(t[1], self.s_pw0, P("W"))
+        p.s_add_i32(t[1], t[1], 1)
+        p.s_cmp("le_i32", self.s_k0, t[1])
+        p.s_cselect(t[1], 1, 0)
+        p.s_cmp("lg_u32", t[0], t[1])                  # exactly one of the two
+        p.s_cbranch("scc0", "L_edge%=")
+        p.s_cmp("lg_u32", t[0], 0)
+        p.s_cbranch("scc1", "L_edge_d%=")
+        p.s_branch("L_edge_w%=")
         return p
 
     def emit_tile_advance(self, p: Prog):
@@ -821,7 +855,7 @@ class DqGen(WorkList):
         items = []
         items += finish_block(self.prologue_pk().items)
         items += insert_waits(self.loop_top().items)
-        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()) + (((4, "L_sinkfar%="),) if self.sinkfar else ()):
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()) + (((4, "L_sinkfar%="),) if self.sinkfar else ()) + (((5, "L_edge_d%="), (6, "L_edge_w%=")) if self.edge_subs else ()):
             body = self.tile_body(cls).items
             items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:
@@ -830,6 +864,8 @@ class DqGen(WorkList):
             body = fix_hazards(body, loop=True)
             items += body
             items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        if self.edge_subs:
+            items += finish_block(self.edge_selector().items)
         # ---- item transition: the next item's requests go out BEFORE the finished item's stores are formed
         p = Prog()
         p.label("L_done%=")
@@ -882,7 +918,7 @@ class DqGen(WorkList):
         items = []
         items += finish_block(self.prologue().items)
         items += insert_waits(self.loop_top().items)
-        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()) + (((4, "L_sinkfar%="),) if self.sinkfar else ()):
+        for cls, lbl in ((0, "L_full%="), (1, "L_edge%="), (2, "L_sink%=")) + (((3, "L_dead%="),) if self.dead else ()) + (((4, "L_sinkfar%="),) if self.sinkfar else ()) + (((5, "L_edge_d%="), (6, "L_edge_w%=")) if self.edge_subs else ()):
             body = self.tile_body(cls).items
             items.append(Instr("label", mods={"label": lbl}, kind="label", cost=0))
             if self.do_sched:
@@ -891,6 +927,8 @@ class DqGen(WorkList):
             body = fix_hazards(body, loop=True)
             items += body
             items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
+        if self.edge_subs:
+            items += finish_block(self.edge_selector().items)
         items += finish_block(self.epilogue().items)
         return items
 
