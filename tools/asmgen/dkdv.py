@@ -18,7 +18,9 @@ machine mapping:
   is placed into the gaps by tools/asmgen/sched.py.
   Q / dO slices (and the 64 row constants) arrive by LDS-DMA three slices ahead into a 4-deep ring; one s_barrier per
   trip; the wave's V rows sit in LDS for the whole workgroup, its K fragments in registers.
-  Three trip bodies per wave: "full" (no mask instructions), "edge" (per-element masks) and "dead" - no row of the slice sees
+  Trip bodies per wave: "full" (no mask instructions; the only class the scheduled bodies compute for the next trip - everything
+  else is told apart by a scalar selector behind the loop head that only non-full trips reach), "edge" (per-element masks), edge
+  on ONE of the wave's two 32-key blocks (the other is out of every row's reach) and "dead" - no row of the slice sees
   any key of the wave (the block's sweep covers the rows that ANY of its 256 keys can see: a wave's 64 keys are out of reach
   in 6 of them per q head): the wave issues its LDS-DMA pieces, keeps its state and waits at the barrier.  Same results bit
   for bit; C3 dK/dV -2.9 %, W = 1024 -4 ... -8 %, W = 128 -9 % (in-process A/B, profiles/r03_ab_dkdv_dead.log): the idle
@@ -257,8 +259,8 @@ class DkdvGen:
         p.s_cselect(t1, 1, 0)
         p.s_or_b32(t1, t1, self.s_allsink)
         p.s_and_b32(self.s_full, t0, t1)
-        if self.dead:
-            t2 = self.s_tmp[0]
+        if self.dead and not self.half_edges:       # (with half_edges the selector behind the loop head finds the dead trips: nothing
+            t2 = self.s_tmp[0]                      # of this in the scheduled bodies)
             p.s_add_u32(t1, self.s_q0p, 94)
             p.s_cmp("gt_i32", self.s_kw63, t1)                  # kw0 = kw63 - 63 > q0p + 31
             p.s_cselect(t0, 1, 0)
@@ -516,7 +518,7 @@ class DkdvGen:
             p.v_add_u32(self.v_sum[2], 1, self.v_sum[2])
             p.s_cmp("lg_u32", self.s_tmp[3], 0)
         p.s_cbranch("scc0", "L_edgesel%=" if self.half_edges else "L_edge%=")
-        if self.dead:
+        if self.dead and not self.half_edges:
             p.s_cmp("eq_u32", self.s_tmp[3] if self.stamps else self.s_full, 2)
             p.s_cbranch("scc1", "L_dead%=")
         return p
@@ -551,6 +553,10 @@ class DkdvGen:
                 p.s_cselect(t1, 1, 0)
                 p.s_and_b32(t0, t0, t1)
                 p.s_or_b32(acc, acc, t0)
+            if self.dead:
+                p.s_and_b32(t0, t2, t3)
+                p.s_cmp("lg_u32", t0, 0)
+                p.s_cbranch("scc1", "L_dead%=")                    # both: the wave has nothing to do in this trip
             p.s_cmp("lg_u32", t3, 0)
             p.s_cbranch("scc1", "L_e0%=")                          # second block dead: the first one alone
             p.s_cmp("lg_u32", t2, 0)
