@@ -216,7 +216,7 @@ class DqGen(WorkList):
         p.s_cselect(t[1], 2, 1)
         p.s_cmp("lg_u32", t[0], 0)
         p.s_cselect(self.s_cls, 0, t[1])
-        if self.dead:
+        if self.dead and not self.edge_subs:       # (with edge_subs the selector behind the loop head finds the dead tiles)
             # 3: no row of the wave sees any key of the tile - every key lies behind every row (k0 > pwhi), or the tile holds
             # no sink key and every key has left every row's window (k0 + 63 <= pw0 - W): waves that own different ROWS
             # (MHA, groups of 2) walk tiles that only the other waves' rows can see (fwd.py, class 4)
@@ -389,7 +389,7 @@ class DqGen(WorkList):
         p.s_cbranch("scc1", "L_full%=")
         p.s_cmp("eq_u32", self.s_cls, 1)
         p.s_cbranch("scc1", "L_edgesel%=" if self.edge_subs else "L_edge%=")
-        if self.dead:
+        if self.dead and not self.edge_subs:
             p.s_cmp("eq_u32", self.s_cls, 3)
             p.s_cbranch("scc1", "L_dead%=")
         if self.sinkfar:
@@ -522,6 +522,16 @@ class DqGen(WorkList):
         p = Prog()
         t = self.s_tmp
         p.label("L_edgesel%=")
+        if self.dead:
+            # no row of the wave sees any key of the tile: every key lies behind every row (k0 > pwhi), or every key has left
+            # every row's window (k0 + 63 <= pw0 - W; class 1 tiles hold no sink key) - waves that own different ROWS (MHA,
+            # groups of 2) walk tiles that only the other waves' rows can see
+            p.s_cmp("gt_i32", self.s_k0, self.s_pwhi)
+            p.s_cbranch("scc1", "L_dead%=")
+            p.s_sub_i32(t[1], self.s_pw0, P("W"))
+            p.s_add_u32(t[2], self.s_k0, 63)
+            p.s_cmp("le_i32", t[2], t[1])
+            p.s_cbranch("scc1", "L_dead%=")
         p.s_cmp("ge_i32", self.s_k0, self.s_pw0)
         p.s_cselect(t[0], 1, 0)
         p.s_sub_i32(t[1], self.s_pw0, P("W"))

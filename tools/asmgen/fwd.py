@@ -68,6 +68,7 @@ class FwdGen(WorkList):
         self.dma_t0, self.dma_dt = dma_t0, dma_dt
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dead = dead                  # tile class 4 (emit_class) and the iteration bodies that skip dead tiles
+        self.dead_sel = True              # ... found by a selector behind the loop head that only edge tiles reach, not by every body
         # an item's sink tile without the exp2 / PV of its second key half when nobody sees it: measured no faster (C3 forward
         # 1.458 vs 1.445 ms, window 512 0.383 vs 0.383, in-process): off; the dQ kernel's version of it pays (dq.py)
         self.sinkfar = sinkfar and persist and dead
@@ -187,7 +188,7 @@ class FwdGen(WorkList):
         p.s_cselect(t[1], 2, 1)
         p.s_cmp("lg_u32", t[0], 0)
         p.s_cselect(self.s_cls, 0, t[1])
-        if self.dead:
+        if self.dead and not self.dead_sel:
             # 4: no row of the wave sees any key of the tile - every key lies behind every row (k0 > pwhi), or the tile holds
             # no sink key and every key has left every row's window (k0 + 63 <= pw0 - W).  Workgroups whose waves own
             # different ROWS (MHA, groups of 2: 4 / hpw row groups) walk tiles that only the other waves' rows can see.
@@ -536,10 +537,33 @@ class FwdGen(WorkList):
             p.s_waitcnt(vmcnt=4 * self.HALVES, note="tile it+1 landed (own pieces); tile it+2 may be in flight")
             p.s_barrier()
         codes = self.body_codes()
+        if self.dead and self.dead_sel:
+            codes = [c for c in codes if (c & 7) != 4]          # the dead-next bodies are entered through the selectors
         for code in codes[:-1]:
             p.s_cmp("eq_u32", self.s_cls, code)
-            p.s_cbranch("scc1", "L_body%d%%=" % code)
-        p.s_branch("L_body%d%%=" % codes[-1])
+            p.s_cbranch("scc1", ("L_sel%d%%=" if (self.dead and self.dead_sel and (code & 7) == 1) else "L_body%d%%=") % code)
+        last = codes[-1]
+        p.s_branch(("L_sel%d%%=" if (self.dead and self.dead_sel and (last & 7) == 1) else "L_body%d%%=") % last)
+        return p
+
+    def dead_selectors(self) -> Prog:
+        """behind the loop head, for iterations whose NEXT tile is an edge tile without sink keys: is it out of reach of every
+        row of the wave - every key behind every row (k0n > pwhi) or past every row's window (k0n + 63 <= pw0 - W)?  Then the
+        body without its S^T chains and softmax bookkeeping (class 4), else the edge body.  Waves that own different ROWS (MHA,
+        groups of 2) walk tiles that only the other waves' rows can see; the scheduled bodies carry none of this test."""
+        p = Prog()
+        t = self.s_tmp
+        for code in self.body_codes():
+            if (code & 7) != 1:
+                continue
+            p.label("L_sel%d%%=" % code)
+            p.s_cmp("gt_i32", self.s_k0n, self.s_pwhi)
+            p.s_cbranch("scc1", "L_body%d%%=" % (code + 3))
+            p.s_sub_i32(t[1], self.s_pw0, P("W"))
+            p.s_add_u32(t[2], self.s_k0n, 63)
+            p.s_cmp("le_i32", t[2], t[1])
+            p.s_cbranch("scc1", "L_body%d%%=" % (code + 3))
+            p.s_branch("L_body%d%%=" % code)
         return p
 
     def body_codes(self):
@@ -986,6 +1010,8 @@ class FwdGen(WorkList):
                 items += b
                 items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
         items += finish_block(self.rescale().items)
+        if self.dead and self.dead_sel:
+            items += finish_block(self.dead_selectors().items)
         # ---- item transition: the next item's Q requests go out BEFORE the finished item's stores are formed
         p = Prog()
         p.label("L_done%=")
@@ -1029,6 +1055,8 @@ class FwdGen(WorkList):
                     items.append(Instr("s_waitcnt", kind="wait", mods={"lgkmcnt": 0}))
                 items.append(Instr("s_branch", mods={"label": "L_top%="}, kind="branch"))
         items += finish_block(self.rescale().items)
+        if self.dead and self.dead_sel:
+            items += finish_block(self.dead_selectors().items)
         items += finish_block(self.epilogue().items)
         return items
 
