@@ -137,6 +137,7 @@ class DkdvGen:
         self.s_ldq, self.s_ldh, self.s_ldrow = sa("s_ldq"), sa("s_ldh"), sa("s_ldrow")
         self.s_cq, self.s_q0p = sa("s_cq"), sa("s_q0p")
         self.s_kw63, self.s_kww, self.s_allsink = sa("s_kw63"), sa("s_kww"), sa("s_allsink")
+        self.s_frng = self.s_allsink       # half_edges: the length of the wave's "full" range of q0p (the flag is folded into it)
         self.s_stepq, self.s_stepd = sa("s_stepq"), sa("s_stepd")     # 32 rows in bytes
         self.s_spanq, self.s_spand, self.s_spanc = sa("s_spanq"), sa("s_spand"), sa("s_spanc")
         self.s_wofs = sa("s_wofs")                # 2048 * wave: the wave's two DMA pieces inside a slice image
@@ -252,6 +253,13 @@ class DkdvGen:
         sink key and every key has left every row's window (q0p - kw63 >= W) - the trips a wave spends on slices that only
         the OTHER waves' keys can see (6 of every sweep in lock step); else 0 (edge: per-element masks)"""
         t0, t1 = self.s_tmp[1], self.s_tmp[2]
+        if self.half_edges:
+            # (the only class the scheduled bodies need is "full": q0p in [kw63, kw0 + W - 32] - or [kw63, oo) for a wave of
+            # sink keys only -, one unsigned compare against a per-wave constant; the selector tells the rest apart)
+            p.s_sub_u32(t0, self.s_q0p, self.s_kw63)
+            p.s_cmp("lt_u32", t0, self.s_frng)
+            p.s_cselect(self.s_full, 1, 0)
+            return
         p.s_cmp("le_i32", self.s_kw63, self.s_q0p)
         p.s_cselect(t0, 1, 0)
         p.s_add_u32(t1, self.s_q0p, 31)
@@ -406,6 +414,12 @@ class DkdvGen:
         p.s_add_u32(self.s_kww, self.s_tmp[0], P("W"))
         p.s_cmp("lt_i32", self.s_kw63, P("ns"))
         p.s_cselect(self.s_allsink, 1, 0)
+        if self.half_edges:
+            # full <=> kw63 <= q0p and (all sinks or kw0 + W > q0p + 31): q0p - kw63 <u (kw0 + W - 31) - kw63 = W - 94, or <u 2^31
+            p.s_sub_i32(self.s_tmp[1], P("W"), 94)
+            p.s_max_i32(self.s_tmp[1], self.s_tmp[1], 0)
+            p.s_cmp("lg_u32", self.s_allsink, 0)
+            p.s_cselect(self.s_frng, 0x7FFFFFFF, self.s_tmp[1])
 
         # ---- slice stream: source offsets of this wave's pieces.  piece (2 wave + e): rows 8 wave + rr, 16-byte chunk
         #      4 (2 e + cbl) + (slot ^ ((2 wave + (rr >> 2)) & 3))

@@ -69,6 +69,9 @@ class FwdGen(WorkList):
         self.ablate = set(ablate)         # timing-only knock-out builds (wrong results)
         self.dead = dead                  # tile class 4 (emit_class) and the iteration bodies that skip dead tiles
         self.dead_sel = True              # ... found by a selector behind the loop head that only edge tiles reach, not by every body
+        # ... which can also tell sink tiles from edge tiles, so that the bodies compute "full or not" only (12 scalar
+        # instructions fewer per iteration): measured no faster (C3 forward 1.484 vs 1.477 ms, same box), off
+        self.range_cls = False
         # an item's sink tile without the exp2 / PV of its second key half when nobody sees it: measured no faster (C3 forward
         # 1.458 vs 1.445 ms, window 512 0.383 vs 0.383, in-process): off; the dQ kernel's version of it pays (dq.py)
         self.sinkfar = sinkfar and persist and dead
@@ -112,6 +115,7 @@ class FwdGen(WorkList):
         self.s_f0 = sa("s_f0", 2, 2)
         self.s_wave, self.s_hh, self.s_rgi = sa("s_wave"), sa("s_hh"), sa("s_rgi")
         self.s_pw0, self.s_pwhi = sa("s_pw0"), sa("s_pwhi")
+        self.s_flo, self.s_frng = sa("s_flo"), sa("s_frng")        # tiles starting in [flo, flo + frng) are "full" for this wave
         self.s_it, self.s_k0n = sa("s_it"), sa("s_k0n")
         self.s_st, self.s_stn, self.s_std = sa("s_st"), sa("s_stn"), sa("s_std")
         self.s_koff, self.s_voff = sa("s_koff"), sa("s_voff")
@@ -173,6 +177,14 @@ class FwdGen(WorkList):
     def emit_class(self, p: Prog, k0):
         """s_cls of the tile starting at key k0: 0 full, 1 edge (no sink key in the tile), 2 edge with sink keys, 4 dead"""
         t = self.s_tmp
+        if self.range_cls:
+            # the scheduled bodies only ask "full or not": every key causal for every row and inside every row's window <=>
+            # pwhi - W + 1 <= k0 <= pw0 - 63, one unsigned compare against two per-item constants; the selector behind the loop
+            # head tells the rest apart (edge / sink keys / dead), for the tiles that are not full
+            p.s_sub_u32(t[0], k0, self.s_flo)
+            p.s_cmp("lt_u32", t[0], self.s_frng)
+            p.s_cselect(self.s_cls, 0, 1)
+            return
         p.s_add_u32(t[0], k0, 63)
         p.s_cmp("le_i32", t[0], self.s_pw0)
         p.s_cselect(t[1], 1, 0)
@@ -557,6 +569,18 @@ class FwdGen(WorkList):
             if (code & 7) != 1:
                 continue
             p.label("L_sel%d%%=" % code)
+            if self.range_cls:
+                # a tile with sink keys: all of them sinks and causal for every row - full after all; else the sink-edge body
+                l_ns = "L_selns%d%%=" % code
+                p.s_cmp("lt_i32", self.s_k0n, P("ns"))
+                p.s_cbranch("scc0", l_ns)
+                p.s_add_u32(t[2], self.s_k0n, 63)
+                p.s_cmp("lt_i32", t[2], P("ns"))
+                p.s_cbranch("scc0", "L_body%d%%=" % (code + 1))
+                p.s_cmp("le_i32", t[2], self.s_pw0)
+                p.s_cbranch("scc1", "L_body%d%%=" % (code - 1))
+                p.s_branch("L_body%d%%=" % (code + 1))
+                p.label(l_ns)
             p.s_cmp("gt_i32", self.s_k0n, self.s_pwhi)
             p.s_cbranch("scc1", "L_body%d%%=" % (code + 3))
             p.s_sub_i32(t[1], self.s_pw0, P("W"))
@@ -819,6 +843,12 @@ class FwdGen(WorkList):
         p.s_sub_u32(st[2], st[4], 1)
         p.s_min_i32(st[1], st[1], st[2])
         p.s_add_u32(self.s_pwhi, st[1], P("pos0"))
+        if self.range_cls:
+            p.s_sub_i32(self.s_flo, self.s_pwhi, P("W"))
+            p.s_add_i32(self.s_flo, self.s_flo, 1)
+            p.s_sub_i32(st[1], self.s_pw0, self.s_flo)
+            p.s_sub_i32(st[1], st[1], 62)
+            p.s_max_i32(self.s_frng, st[1], 0)
         p.v_add_u32(t0, st[0], self.lane31)                   # row, rb = 0
         p.v_add_u32(self.v_pos[0], P("pos0"), t0)
         p.v_add_u32(self.v_pos[1], 32, self.v_pos[0])
